@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REFERENCE ITSELF (run in the build container only).
+
+TEST INFRASTRUCTURE.  Runs the reference's res/shaders/rt.comp (read from --reference-dir, patched
+in memory by oracle/llvmpipe_runner.c, never copied) under headless Mesa llvmpipe and stores its
+outputs as small fixtures; also parses the reference's res/meshes/bunny1.obj into arrays
+(path_tracer_amd/data/bunny1.npz: input data, not code) and asks the reference's vendored GLM for
+camera matrices (oracle/_ref/glm_camera_ref).  The GPU box has no /root/reference: tests there
+read only what this script wrote.
+
+    python oracle/gen_goldens.py [--reference-dir /root/reference] [--only NAME ...]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from path_tracer_amd import scene as S  # noqa: E402  (scene *inputs* only; no renderer is imported)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+RUNNER = os.path.join(ROOT, "oracle", "_ref", "llvmpipe_runner")
+GLMCAM = os.path.join(ROOT, "oracle", "_ref", "glm_camera_ref")
+f32 = np.float32
+
+
+def scene_blob(sc: S.Scene) -> bytes:
+    hdr = struct.pack("<6I", 0x31435350, len(sc.mesh_tris), len(sc.nodes), len(sc.materials), len(sc.spheres), len(sc.triangles))
+    return hdr + sc.mesh_tris.tobytes() + sc.nodes.tobytes() + sc.materials.tobytes() + sc.spheres.tobytes() + sc.triangles.tobytes()
+
+
+def run_reference(refdir, sc, cam, W, H, passes, bounces, first_pass=1, dump=0, debug_normal=0, every=False, threads=None, dump_bounce=0):
+    """-> (images (n,H,W,4) float32, timing dict).  Row 0 = bottom row (GL origin)."""
+    with tempfile.TemporaryDirectory() as td:
+        sp, op = os.path.join(td, "scene.bin"), os.path.join(td, "out.bin")
+        with open(sp, "wb") as fh:
+            fh.write(scene_blob(sc))
+        cmd = [RUNNER, "--reference-dir", refdir, "--scene", sp, "--out", op, "--width", str(W), "--height", str(H),
+               "--passes", str(passes), "--first-pass", str(first_pass), "--bounces", str(bounces), "--dump", str(dump),
+               "--debug-normal", str(debug_normal), "--quiet", "--dump-bounce", str(dump_bounce),
+               "--cam-pos", *[f"{v:.9g}" for v in np.asarray(cam.position, f32)],
+               "--inv-view", *[f"{v:.9g}" for v in cam.inv_view_flat()]]
+        if every:
+            cmd.append("--dump-every-pass")
+        env = dict(os.environ)
+        if threads:
+            env["LP_NUM_THREADS"] = str(threads)
+        r = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env)
+        img = np.fromfile(op, dtype=f32).reshape(-1, H, W, 4)
+        return img, json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def crc(a: np.ndarray) -> int:
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def glm_cameras(cams):
+    args = []
+    for (pos, yaw, pitch) in cams:
+        args += [f"{v:.9g}" for v in pos] + [f"{yaw:.9g}", f"{pitch:.9g}"]
+    out = subprocess.run([GLMCAM, *args], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    res = []
+    for (pos, yaw, pitch), line in zip(cams, out):
+        w = line.split()
+        res.append({"position": list(map(float, pos)), "yaw": yaw, "pitch": pitch, "position_bits": w[:3], "inverse_view_bits": w[3:]})
+    return res
+
+
+def cam_from_bits(entry) -> S.Camera:
+    c = S.Camera(position=np.array([int(b, 16) for b in entry["position_bits"]], np.uint32).view(f32), yaw=entry["yaw"], pitch=entry["pitch"])
+    c.inverseView = np.array([int(b, 16) for b in entry["inverse_view_bits"]], np.uint32).view(f32).reshape(4, 4)
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference-dir", default="/root/reference")
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    ref = a.reference_dir
+    os.makedirs(GOLD, exist_ok=True)
+    want = lambda name: a.only is None or name in a.only
+
+    # ---- input data: the default mesh, parsed (meshes are inputs) -------------
+    if want("mesh"):
+        v, fidx = S.load_obj(os.path.join(ref, "res", "meshes", "bunny1.obj"))
+        os.makedirs(os.path.join(ROOT, "path_tracer_amd", "data"), exist_ok=True)
+        np.savez_compressed(os.path.join(ROOT, "path_tracer_amd", "data", "bunny1.npz"), vertices=v, faces=fidx)
+        print("mesh: bunny1", v.shape, fidx.shape)
+
+    # ---- camera matrices from the reference's GLM ---------------------------------------------
+    cam_specs = [((0.0, 0.0, 0.0), 0.0, 0.0), ((1.5, 0.4, 0.0), 0.0, 0.0), ((1.5, 0.8, 1.5), 45.0, 20.0),
+                 ((1.2, 0.9, 0.8), 33.0, 24.0), ((-2.0, 1.1, 0.7), 170.0, -35.0), ((0.3, 2.5, -1.9), -100.0, 89.0)]
+    cams = glm_cameras(cam_specs)
+    if want("camera"):
+        with open(os.path.join(GOLD, "camera.json"), "w") as fh:
+            json.dump({"source": "reference GLM 0.9.8.5 via oracle/glm_camera_ref.cpp (call sequence of src/Camera.cpp:13-26)",
+                       "cameras": cams}, fh, indent=1)
+        print("camera:", len(cams))
+    bench_cam, mixed_cam, rot_cam = cam_from_bits(cams[1]), cam_from_bits(cams[2]), cam_from_bits(cams[3])
+
+    dsc, msc = S.default_scene(), S.mixed_scene()
+    meta = {"generator": "oracle/gen_goldens.py", "oracle": "reference res/shaders/rt.comp under Mesa llvmpipe (oracle/llvmpipe_runner.c)",
+            "row0": "bottom image row (GL texel origin)", "entries": {}}
+    meta_path = os.path.join(GOLD, "meta.json")
+    if os.path.exists(meta_path) and a.only is not None:
+        meta = json.load(open(meta_path))
+
+    # ---- 1. seeds / rng state / primary directions / primary ids ------------------------------
+    if want("primary"):
+        arrs = {}
+        for tag, sc, cam in (("default", dsc, bench_cam), ("default_rot", dsc, rot_cam), ("mixed", msc, mixed_cam)):
+            for (W, H) in ((64, 40), (640, 360), (1920, 1080), (3840, 2160)):
+                if (W, H) == (3840, 2160) and tag != "default":
+                    continue
+                for p in ((1, 7) if (W, H) != (3840, 2160) else (1,)):
+                    ids_img, _ = run_reference(ref, sc, cam, W, H, 1, 3, first_pass=p, dump=1)
+                    dir_img, _ = run_reference(ref, sc, cam, W, H, 1, 3, first_pass=p, dump=2)
+                    ids = ids_img[0, :, :, 0].astype(np.int32)
+                    tdist = ids_img[0, :, :, 1].copy()
+                    front = ids_img[0, :, :, 2].astype(np.uint8)
+                    rng = ids_img[0, :, :, 3].copy().view(np.uint32)
+                    dirs = dir_img[0, :, :, :3].copy()
+                    pix = dir_img[0, :, :, 3].copy().view(np.uint32)
+                    key = f"{tag}_{W}x{H}_p{p}"
+                    meta["entries"]["primary_" + key] = {
+                        "crc_ids": crc(ids), "crc_t": crc(tdist), "crc_front": crc(front), "crc_rng_after_jitter": crc(rng),
+                        "crc_dirs": crc(dirs), "crc_pixel_index": crc(pix), "n_hits": int((ids >= 0).sum()),
+                        "n_distinct_seeds": int(len(np.unique(pix)))}
+                    if (W, H) == (64, 40):
+                        arrs[key + "_ids"], arrs[key + "_t"], arrs[key + "_rng"] = ids.astype(np.int16), tdist, rng
+                        arrs[key + "_dirs"], arrs[key + "_pix"] = dirs, pix
+                    if (W, H) == (640, 360) and p == 1:
+                        arrs[key + "_ids"] = ids.astype(np.int16)
+                    print("primary", key, meta["entries"]["primary_" + key]["n_hits"])
+        np.savez_compressed(os.path.join(GOLD, "primary.npz"), **arrs)
+
+    # ---- 2. debugNormal image ------------------------------------------------------------------
+    if want("normal"):
+        arrs = {}
+        for tag, sc, cam in (("default", dsc, bench_cam), ("mixed", msc, mixed_cam)):
+            img, _ = run_reference(ref, sc, cam, 128, 72, 1, 3, debug_normal=1)
+            arrs[f"{tag}_128x72"] = img[0, :, :, :3].copy()
+            img, _ = run_reference(ref, sc, cam, 640, 360, 1, 3, debug_normal=1)
+            meta["entries"][f"normal_{tag}_640x360"] = {"crc_rgb": crc(img[0, :, :, :3])}
+        np.savez_compressed(os.path.join(GOLD, "debug_normal.npz"), **arrs)
+        print("normal done")
+
+    # ---- 3. radiance: per-pass 1-spp and running means ----------------------------------------
+    if want("radiance"):
+        arrs = {}
+        for tag, sc, cam, bounces_list in (("default", dsc, bench_cam, (3, 4, 8)), ("default_rot", dsc, rot_cam, (4,)),
+                                           ("mixed", msc, mixed_cam, (3, 16))):
+            for b in bounces_list:
+                W, H = 128, 72
+                # 1-spp radiance of passes 1..4 taken separately (fresh accumulation image each time: pass k on a
+                # zero image gives prev + (1/k)*(c - 0), so run each as its own "first" only for k = 1; for k > 1 we
+                # recover nothing exact that way -> instead store the running mean after every pass)
+                img, _ = run_reference(ref, sc, cam, W, H, 16, b, every=True)
+                for k in (1, 2, 3, 4, 16):
+                    arrs[f"{tag}_b{b}_{W}x{H}_mean{k}"] = img[k - 1, :, :, :3].copy()
+                assert np.all(img[:, :, :, 3] == 1.0)
+                print("radiance", tag, b)
+        np.savez_compressed(os.path.join(GOLD, "radiance_128x72.npz"), **arrs)
+        # config 1 exactly: 640x360, 16 spp, 4 bounces, default scene (BASELINE.json configs[0])
+        img, tm = run_reference(ref, dsc, bench_cam, 640, 360, 16, 4, every=True)
+        e = {"crc_mean1": crc(img[0, :, :, :3]), "crc_mean2": crc(img[1, :, :, :3]), "crc_mean16": crc(img[15, :, :, :3]),
+             "llvmpipe_timing": tm, "lp_threads": os.environ.get("LP_NUM_THREADS", "unset"), "host_cpus": os.cpu_count()}
+        meta["entries"]["radiance_default_b4_640x360"] = e
+        # keep every 8th row of the 16-spp mean for a diagnosable comparison
+        np.savez_compressed(os.path.join(GOLD, "radiance_c1_rows.npz"), mean16_rows8=img[15, ::8, :, :3].copy(), mean1_rows8=img[0, ::8, :, :3].copy())
+        img, tm = run_reference(ref, msc, mixed_cam, 640, 360, 4, 16, every=True)
+        meta["entries"]["radiance_mixed_b16_640x360"] = {"crc_mean1": crc(img[0, :, :, :3]), "crc_mean4": crc(img[3, :, :, :3]), "llvmpipe_timing": tm}
+        print("radiance c1", e)
+
+    # ---- 3b. per-bounce path state (instrumented shader, llvmpipe_runner --dump 3/4) -----------
+    if want("bounce"):
+        arrs = {}
+        for tag, sc, cam in (("mixed", msc, mixed_cam), ("default", dsc, bench_cam)):
+            for i in range(5):
+                d3, _ = run_reference(ref, sc, cam, 64, 40, 1, 6, first_pass=2, dump=3, dump_bounce=i)
+                d4, _ = run_reference(ref, sc, cam, 64, 40, 1, 6, first_pass=2, dump=4, dump_bounce=i)
+                arrs[f"{tag}_64x40_p2_b{i}_origin_rng"] = d3[0].copy()      # xyz = origin after bounce i, w = rng state bits; -7 = path ended
+                arrs[f"{tag}_64x40_p2_b{i}_dir_t"] = d4[0].copy()           # xyz = direction after bounce i, w = hitDist of bounce i
+        np.savez_compressed(os.path.join(GOLD, "bounce_state.npz"), **arrs)
+        print("bounce done")
+
+    # ---- 4. arithmetic probe (our shader): RNG, log, cos, Box-Muller samples -------------------
+    if want("arith"):
+        with tempfile.TemporaryDirectory() as td:
+            op = os.path.join(td, "o.bin")
+            subprocess.run([RUNNER, "--shader-file", os.path.join(ROOT, "oracle", "probes", "arith_probe.comp"), "--width", "128",
+                            "--height", "64", "--passes", "11", "--dump-every-pass", "--quiet", "--out", op], check=True, capture_output=True)
+            d = np.fromfile(op, dtype=f32).reshape(11, 128 * 64, 4)
+        np.savez_compressed(os.path.join(GOLD, "arith_probe.npz"),
+                            u=d[0][:, 0].copy(), u2=d[0][:, 1].copy(), log_u=d[3][:, 0].copy(), cos_2pi_u=d[3][:, 1].copy(),
+                            sqrt_m2log_u=d[3][:, 3].copy(), nd_u_u2=d[4][:, 0].copy(),
+                            sweep_w=d[9][:, 0].copy(), sweep_log=d[9][:, 1].copy(), sweep_cos=d[9][:, 2].copy())
+        print("arith done")
+
+    with open(meta_path, "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+    print("wrote", meta_path)
+
+
+if __name__ == "__main__":
+    main()
