@@ -1,0 +1,123 @@
+/*
+ * pt_hip.h — C ABI of the MI355X-native path-tracing hot path (libpt_hip.so).
+ *
+ * This is the drop-in boundary for the reference's per-pixel path-tracing loop
+ * (res/shaders/rt.comp, dispatched at src/Main.cpp:148).  The reference has no plugin API; its
+ * de-facto operator interface is the set of GL calls the host makes to feed and launch that
+ * shader.  Every entry point below names the reference call site it replaces.
+ *
+ * Conventions: plain C, opaque handle, every call returns 0 on success or a negative PT_E_* code;
+ * pt_last_error() gives the text.  Records are the reference's own host structs, byte for byte
+ * (src/Object.h:8-75 == std430 layout in rt.comp:33-48); uploads copy, the caller keeps ownership.
+ * One host thread per context; calls on one context are not re-entrant (the reference drives its
+ * GL context from one thread, src/Main.cpp:108-170).  Work is enqueued on the context's HIP
+ * stream; pt_read_* and pt_synchronize wait for it.
+ * There is NO CPU fallback: every entry point fails if no HIP device is usable.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_E_INVALID (-1)   /* bad argument / call order */
+#define PT_E_HIP (-2)       /* a HIP runtime call failed */
+#define PT_E_STATE (-3)     /* scene, camera or image size not set yet */
+#define PT_E_LIMIT (-4)     /* size beyond a documented maximum */
+
+/* src/Object.h:8-21  (80 B; rt.comp:33-44) */
+typedef struct PtMaterial {
+    float baseColor[4], specularColor[4], emissionColor[4];
+    float smoothness, specularSmoothness, emissionStrength, ior, refractionAmount, specularChance;
+    int32_t pad[2];
+} PtMaterial;
+/* src/Object.h:23-33  (32 B; rt.comp:45) */
+typedef struct PtSphere { float position[3]; float radius; uint32_t materialIndex; int32_t pad[3]; } PtSphere;
+/* src/Object.h:35-48  (64 B; rt.comp:46) */
+typedef struct PtTriangle { float p1[4], p2[4], p3[4]; uint32_t materialIndex; int32_t pad[3]; } PtTriangle;
+/* src/Object.h:63-75  (48 B; rt.comp:48) */
+typedef struct PtNode { float boundsMin[4], boundsMax[4]; int32_t triIndex, numTris, childrenIndex, pad; } PtNode;
+
+typedef struct pt_ctx pt_ctx;
+
+/* Work actually executed by the kernels since the last pt_reset_counters (for the roofline). */
+typedef struct PtCounters {
+    uint64_t samples;        /* primary rays traced                                             */
+    uint64_t segments;       /* CalculateRay() calls (rt.comp:271)                              */
+    uint64_t mesh_segments;  /* segments that passed the root-AABB gate (rt.comp:213)           */
+    uint64_t mesh_tri_tests; /* ray-triangle tests against mesh triangles, padded slots included */
+} PtCounters;
+
+/* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */
+int pt_create(pt_ctx **out, int device);
+void pt_destroy(pt_ctx *ctx);
+const char *pt_last_error(const pt_ctx *ctx);            /* ctx may be NULL: last pt_create error */
+/* accumulation image RGBA32F W x H, zero-filled (glTexImage2D GL_RGBA32F, src/Renderer.cpp:117-128).
+ * Like glDispatchCompute(W/8, H/8, 1) (src/Main.cpp:148) only the (W/8)*8 x (H/8)*8 pixels are traced. */
+int pt_resize(pt_ctx *ctx, int width, int height);
+/* Use caller-owned device memory (W*H*4 floats) as the accumulation image, e.g. a torch tensor that
+ * an RCCL reduce will read.  NULL returns to the internal buffer.  (glBindImageTexture, src/Renderer.cpp:128) */
+int pt_set_accum_buffer(pt_ctx *ctx, void *device_rgba32f, size_t bytes);
+/* hipStream_t to enqueue on (NULL = the context's own stream). */
+int pt_set_stream(pt_ctx *ctx, void *hip_stream);
+
+/* --- scene: Mesh::Mesh binds Triangle[] to SSBO 1 and Node[] to SSBO 2 (src/Object.cpp:97-110);
+ *     only nodes[0] (root AABB) is read by the shader (rt.comp:213).  Device layout is SoA. */
+int pt_upload_mesh(pt_ctx *ctx, const PtTriangle *tris, int n_tris, const PtNode *nodes, int n_nodes);
+/* Scene::SetupSSBOs / UpdateSSBOs: materials -> SSBO 3, spheres -> 4, triangles -> 5 (src/Object.cpp:3-41) */
+int pt_upload_scene(pt_ctx *ctx, const PtMaterial *materials, int n_materials, const PtSphere *spheres, int n_spheres,
+                    const PtTriangle *tris, int n_tris);
+
+/* --- uniforms */
+/* ComputeProgram::SetUniformCamera (src/Shader.cpp:72-76, called src/Main.cpp:146):
+ * cam.position and cam.inverseView (column-major, GL_FALSE transpose) */
+int pt_set_camera(pt_ctx *ctx, const float position[3], const float inverse_view[16]);
+/* SetUniform1i("debugNormal") (src/Main.cpp:128-130; rt.comp:21,23,274) */
+int pt_set_debug_normal(pt_ctx *ctx, int enabled);
+/* the literal 3 at rt.comp:23 (12 in the legacy rt.frag:337); BASELINE configs use 4/8/16 */
+int pt_set_max_bounces(pt_ctx *ctx, int max_bounces);
+
+/* --- tracing */
+/* One accumulation pass == SetUniform1i("currAccumPass", pass) + glDispatchCompute + glMemoryBarrier
+ * (src/Main.cpp:144-150): accum = mix(accum, radiance(pass), 1/pass) (rt.comp:337-339). */
+int pt_render_pass(pt_ctx *ctx, int pass);
+/* Passes first_pass .. first_pass+n_passes-1 in order inside one launch; bit-identical to calling
+ * pt_render_pass for each (the running mean is kept in registers and stored once). */
+int pt_render(pt_ctx *ctx, int first_pass, int n_passes);
+/* Multi-GPU sample split (no reference counterpart; BASELINE.json north_star): adds the plain sum of
+ * the 1-spp radiances of the given passes to the accumulation image (alpha += n_passes) so that
+ * per-GPU buffers can be summed by an RCCL reduce; pt_scale_accum(1/spp) then yields the mean. */
+int pt_render_sum(pt_ctx *ctx, int first_pass, int n_passes);
+int pt_scale_accum(pt_ctx *ctx, float scale, int set_alpha_one);
+/* `currAccumPass = 0` on camera movement + glClear (src/Main.cpp:110-117): zero the accumulation image. */
+int pt_reset(pt_ctx *ctx);
+int pt_synchronize(pt_ctx *ctx);
+
+/* --- results */
+/* the display pass samples accumTexture (compute_accum.frag:9-11, src/Main.cpp:154-156);
+ * here: copy the RGBA32F image to host, row 0 = bottom row (GL texel origin) */
+int pt_read_accum(pt_ctx *ctx, float *rgba, size_t bytes);
+void *pt_accum_device_ptr(pt_ctx *ctx);
+/* Test-only: primary-ray closest hit of `pass` per pixel, canonical ids (mesh i | n_mesh+i |
+ * n_mesh+n_tris+i | -1 = miss), hit distance, normalized ray direction (3 floats/pixel) and the rng
+ * state after the jitter draws.  Any output pointer may be NULL.  (CalculateRay, rt.comp:204-232) */
+int pt_read_primary_hits(pt_ctx *ctx, int pass, int32_t *ids, float *t, float *dirs, uint32_t *rng_states);
+
+/* --- measurement */
+int pt_get_counters(pt_ctx *ctx, PtCounters *out);
+int pt_reset_counters(pt_ctx *ctx);
+/* Device time (ms, HIP events on the context's stream) of the most recent pt_render / pt_render_pass /
+ * pt_render_sum launch; waits for it to finish. */
+int pt_last_render_ms(pt_ctx *ctx, float *ms);
+/* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
+const char *pt_kernel_name(void);
+int pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -65,6 +65,7 @@ def lib():
                                    C.c_void_p, C.POINTER(C.c_int32)]
         L.or_primary_ray.restype = C.c_uint32
         L.or_primary_ray.argtypes = [C.POINTER(OrFrame), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.or_render_region.argtypes = [C.POINTER(OrScene), C.POINTER(OrFrame)] + [C.c_int32] * 6 + [C.c_void_p]
         L.or_num_threads.restype = C.c_int32
     return _lib
 
@@ -89,6 +90,11 @@ class Oracle:
             accum = np.zeros((self.H, self.W, 4), np.float32)
         lib().or_render(C.byref(self.scene), C.byref(self.frame), first_pass, n_passes, accum.ctypes.data)
         return accum
+
+    def render_region(self, first_pass, n_passes, x0, y0, w, h):
+        out = np.zeros((h, w, 4), np.float32)
+        lib().or_render_region(C.byref(self.scene), C.byref(self.frame), first_pass, n_passes, x0, y0, w, h, out.ctypes.data)
+        return out
 
     def radiance_pass(self, p):
         rgb = np.zeros((self.H, self.W, 3), np.float32)

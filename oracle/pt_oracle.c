@@ -385,6 +385,22 @@ void or_render(const OrScene *s, const OrFrame *f, int32_t first_pass, int32_t n
     for (int p = 0; p < n_passes; p++) or_render_pass(s, f, first_pass + p, accum);
 }
 
+/* running mean of passes first..first+n-1 for the w x h window at (x0,y0) of the full frame; out is (h,w,4), zero-based on entry */
+void or_render_region(const OrScene *s, const OrFrame *f, int32_t first_pass, int32_t n_passes, int32_t x0, int32_t y0, int32_t w, int32_t h, float *out)
+{
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float *p = out + 4 * ((size_t)y * w + x);
+            for (int k = 0; k < n_passes; k++) {
+                int pass = first_pass + k;
+                float t = 1.0f / (float)pass;
+                v3 c = sample_pixel(s, f, x0 + x, y0 + y, pass, 0);
+                p[0] = mixf(p[0], c.x, t); p[1] = mixf(p[1], c.y, t); p[2] = mixf(p[2], c.z, t); p[3] = 1.0f;
+            }
+        }
+}
+
 void or_primary_hits(const OrScene *s, const OrFrame *f, int32_t pass, int32_t *ids, float *t, float *dirs, uint32_t *states)
 {
 #pragma omp parallel for schedule(dynamic, 1)

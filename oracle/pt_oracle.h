@@ -63,6 +63,8 @@ void or_ray_trace(const OrScene *s, const OrFrame *f, float o[3], float d[3], ui
 void or_render_pass(const OrScene *s, const OrFrame *f, int32_t pass, float *accum_rgba);
 /* passes first..first+n-1 in order */
 void or_render(const OrScene *s, const OrFrame *f, int32_t first_pass, int32_t n_passes, float *accum_rgba);
+/* same running mean restricted to a window of the full frame (full-size spot checks) */
+void or_render_region(const OrScene *s, const OrFrame *f, int32_t first_pass, int32_t n_passes, int32_t x0, int32_t y0, int32_t w, int32_t h, float *out);
 /* 1-spp radiance of one pass without accumulation (rgb, 3 floats per pixel) */
 void or_radiance_pass(const OrScene *s, const OrFrame *f, int32_t pass, float *rgb);
 /* primary-ray closest hit per pixel: ids (int32), t (float), dirs (3 floats), rng state after jitter; any may be NULL */

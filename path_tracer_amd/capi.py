@@ -1,0 +1,177 @@
+"""ctypes binding of libpt_hip.so (the C ABI declared in include/pt_hip.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.  Importing this module
+never touches the GPU; `load()` fails loudly if the library was not built, and `pt_create` fails if no
+HIP device is usable -- there is no CPU fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+
+PT_OK, PT_E_INVALID, PT_E_HIP, PT_E_STATE, PT_E_LIMIT = 0, -1, -2, -3, -4
+
+# every symbol include/pt_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
+    "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render",
+    "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
+    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_kernel_name", "pt_version",
+]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("mesh_segments", C.c_uint64), ("mesh_tri_tests", C.c_uint64)]
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pt_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """dlopen libpt_hip.so and declare prototypes.  Raises if the HIP library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); path_tracer_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+    L.pt_create.argtypes = [C.POINTER(vp), i32]
+    L.pt_destroy.argtypes = [vp]
+    L.pt_destroy.restype = None
+    L.pt_last_error.argtypes = [vp]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_resize.argtypes = [vp, i32, i32]
+    L.pt_set_accum_buffer.argtypes = [vp, vp, C.c_size_t]
+    L.pt_set_stream.argtypes = [vp, vp]
+    L.pt_upload_mesh.argtypes = [vp, vp, i32, vp, i32]
+    L.pt_upload_scene.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+    L.pt_set_camera.argtypes = [vp, f32p, f32p]
+    L.pt_set_debug_normal.argtypes = [vp, i32]
+    L.pt_set_max_bounces.argtypes = [vp, i32]
+    L.pt_render_pass.argtypes = [vp, i32]
+    L.pt_render.argtypes = [vp, i32, i32]
+    L.pt_render_sum.argtypes = [vp, i32, i32]
+    L.pt_scale_accum.argtypes = [vp, C.c_float, i32]
+    L.pt_reset.argtypes = [vp]
+    L.pt_synchronize.argtypes = [vp]
+    L.pt_read_accum.argtypes = [vp, vp, C.c_size_t]
+    L.pt_accum_device_ptr.argtypes = [vp]
+    L.pt_accum_device_ptr.restype = vp
+    L.pt_read_primary_hits.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pt_get_counters.argtypes = [vp, C.POINTER(PtCounters)]
+    L.pt_reset_counters.argtypes = [vp]
+    L.pt_last_render_ms.argtypes = [vp, f32p]
+    L.pt_kernel_name.restype = C.c_char_p
+    L.pt_version.restype = i32
+    _lib = L
+    return L
+
+
+class Renderer:
+    """Headless counterpart of the reference's `Renderer` namespace + `ComputeProgram` uniform setters
+    (src/Renderer.h:30-45, src/Shader.h:20-37) over the C ABI."""
+
+    def __init__(self, width, height, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.pt_create(C.byref(h), device)
+        if rc:
+            raise PtError(rc, self.L.pt_last_error(None).decode())
+        self.h = h
+        self.screenWidth, self.screenHeight = width, height
+        self._ck(self.L.pt_resize(h, width, height))
+
+    def _ck(self, rc):
+        if rc:
+            raise PtError(rc, self.L.pt_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # --- Object: Mesh ctor + Scene::SetupSSBOs (src/Object.cpp:3-41,89-111)
+    def upload_scene(self, scene):
+        mt, nd = np.ascontiguousarray(scene.mesh_tris), np.ascontiguousarray(scene.nodes)
+        ma, sp, tr = (np.ascontiguousarray(a) for a in (scene.materials, scene.spheres, scene.triangles))
+        self._ck(self.L.pt_upload_mesh(self.h, mt.ctypes.data, len(mt), nd.ctypes.data, len(nd)))
+        self._ck(self.L.pt_upload_scene(self.h, ma.ctypes.data, len(ma), sp.ctypes.data, len(sp), tr.ctypes.data, len(tr)))
+
+    # --- Shader: SetUniformCamera / SetUniform1i (src/Shader.cpp:72-76, src/Main.cpp:128-146)
+    def SetUniformCamera(self, cam):
+        pos = np.ascontiguousarray(cam.position, np.float32)
+        iv = np.ascontiguousarray(cam.inv_view_flat(), np.float32)
+        self._ck(self.L.pt_set_camera(self.h, pos.ctypes.data_as(C.POINTER(C.c_float)), iv.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def SetUniform1i(self, name, value):
+        if name == "debugNormal":
+            self._ck(self.L.pt_set_debug_normal(self.h, int(value)))
+        elif name == "maxBounces":
+            self._ck(self.L.pt_set_max_bounces(self.h, int(value)))
+        else:
+            raise KeyError(name)
+
+    # --- the dispatch (src/Main.cpp:144-150)
+    def render_pass(self, p):
+        self._ck(self.L.pt_render_pass(self.h, p))
+
+    def render(self, first_pass, n_passes):
+        self._ck(self.L.pt_render(self.h, first_pass, n_passes))
+
+    def render_sum(self, first_pass, n_passes):
+        self._ck(self.L.pt_render_sum(self.h, first_pass, n_passes))
+
+    def scale_accum(self, scale, set_alpha_one=True):
+        self._ck(self.L.pt_scale_accum(self.h, scale, int(set_alpha_one)))
+
+    def reset(self):
+        self._ck(self.L.pt_reset(self.h))
+
+    def synchronize(self):
+        self._ck(self.L.pt_synchronize(self.h))
+
+    def set_accum_buffer(self, ptr, nbytes):
+        self._ck(self.L.pt_set_accum_buffer(self.h, ptr, nbytes))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.pt_set_stream(self.h, stream_ptr))
+
+    def read_accum(self):
+        out = np.empty((self.screenHeight, self.screenWidth, 4), np.float32)
+        self._ck(self.L.pt_read_accum(self.h, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_primary_hits(self, p):
+        H, W = self.screenHeight, self.screenWidth
+        ids, t = np.empty((H, W), np.int32), np.empty((H, W), np.float32)
+        dirs, rng = np.empty((H, W, 3), np.float32), np.empty((H, W), np.uint32)
+        self._ck(self.L.pt_read_primary_hits(self.h, p, ids.ctypes.data, t.ctypes.data, dirs.ctypes.data, rng.ctypes.data))
+        return ids, t, dirs, rng
+
+    def counters(self):
+        c = PtCounters()
+        self._ck(self.L.pt_get_counters(self.h, C.byref(c)))
+        return {"samples": c.samples, "segments": c.segments, "mesh_segments": c.mesh_segments, "mesh_tri_tests": c.mesh_tri_tests}
+
+    def reset_counters(self):
+        self._ck(self.L.pt_reset_counters(self.h))
+
+    def last_render_ms(self):
+        ms = C.c_float()
+        self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,449 @@
+// pt_api.hip — C ABI (include/pt_hip.h) over the HIP kernels in pt_kernels.hpp.
+// Host side of the boundary: converts the reference's AoS records (src/Object.h:8-75) into the
+// device SoA/AoS images the kernels read, validates every index the kernels will dereference, and
+// launches on the context's stream.  No CPU rendering path exists here.
+#include "pt_kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+using namespace pt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    hipError_t upload(const void *src, size_t n, hipStream_t s)
+    {
+        if (n > bytes || !p) {
+            if (p) { hipError_t e0 = hipFree(p); if (e0 != hipSuccess) return e0; p = nullptr; bytes = 0; }
+            size_t cap = n ? n : 16;
+            hipError_t e = hipMalloc(&p, cap);
+            if (e != hipSuccess) return e;
+            bytes = cap;
+        }
+        if (n) return hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, s);
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+
+    int width = 0, height = 0;
+    float *accum_own = nullptr; size_t accum_own_bytes = 0;
+    float *accum = nullptr;            // own or external
+    bool accum_external = false;
+
+    DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, counters;
+    int n_mesh = 0, n_chunks = 0, n_tris = 0, n_sph = 0, n_mats = 0;
+    float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    bool have_mesh = false, have_scene = false, have_camera = false;
+    uint32_t max_mat_mesh = 0, max_mat_scene = 0;   // largest material index referenced
+
+    float cam[3] = {0, 0, 0}, iv[9] = {0};
+    int max_bounces = 3;              // rt.comp:23
+    int debug_normal = 0;
+};
+
+namespace {
+
+int fail(pt_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                       \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(c, PT_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+struct Bind { pt_ctx *c; hipError_t e; explicit Bind(pt_ctx *c_) : c(c_), e(hipSetDevice(c_->device)) {} };
+
+inline float3 f3(const float *p) { return make_float3(p[0], p[1], p[2]); }
+
+// host restatement of the per-triangle precomputation; float32, one rounding per op (this TU is
+// compiled with -ffp-contract=off for host and device alike)
+void tri_precompute(const PtTriangle &t, float4 &p1, float4 &e1, float4 &e2, float4 &nr)
+{
+    float e1x = t.p2[0] - t.p1[0], e1y = t.p2[1] - t.p1[1], e1z = t.p2[2] - t.p1[2];
+    float e2x = t.p3[0] - t.p1[0], e2y = t.p3[1] - t.p1[1], e2z = t.p3[2] - t.p1[2];
+    // cross(e2, e1), then normalize(v) = v * (1/sqrt(dot(v,v))), dot summed z,y,x  (rt.comp:171)
+    float cx = e2y * e1z - e2z * e1y, cy = e2z * e1x - e2x * e1z, cz = e2x * e1y - e2y * e1x;
+    float dd = (cz * cz + cy * cy) + cx * cx;
+    float r = 1.0f / sqrtf(dd);
+    uint32_t mi = t.materialIndex; float mf; std::memcpy(&mf, &mi, 4);
+    p1 = make_float4(t.p1[0], t.p1[1], t.p1[2], mf);
+    e1 = make_float4(e1x, e1y, e1z, 0.0f);
+    e2 = make_float4(e2x, e2y, e2z, 0.0f);
+    nr = make_float4(cx * r, cy * r, cz * r, 0.0f);
+}
+
+int check_ready(pt_ctx *c)
+{
+    if (!c) return PT_E_INVALID;
+    if (c->width < 8 || c->height < 8 || !c->accum) return fail(c, PT_E_STATE, "image size not set (pt_resize)");
+    if (!c->have_scene) return fail(c, PT_E_STATE, "scene not uploaded (pt_upload_scene)");
+    if (!c->have_mesh) return fail(c, PT_E_STATE, "mesh not uploaded (pt_upload_mesh; n_tris = 0 is allowed)");
+    if (!c->have_camera) return fail(c, PT_E_STATE, "camera not set (pt_set_camera)");
+    if (c->n_mesh > 0 && c->max_mat_mesh >= (uint32_t)c->n_mats)
+        return fail(c, PT_E_INVALID, "mesh references material %u but only %d materials are uploaded", c->max_mat_mesh, c->n_mats);
+    if ((c->n_tris > 0 || c->n_sph > 0) && c->max_mat_scene >= (uint32_t)c->n_mats)
+        return fail(c, PT_E_INVALID, "scene references material %u but only %d materials are uploaded", c->max_mat_scene, c->n_mats);
+    return PT_OK;
+}
+
+SceneView scene_view(const pt_ctx *c)
+{
+    SceneView s;
+    s.mesh_soa = (const float *)c->mesh_soa.p;
+    s.mesh_p1 = (const float4 *)c->mesh_p1.p; s.mesh_e1 = (const float4 *)c->mesh_e1.p;
+    s.mesh_e2 = (const float4 *)c->mesh_e2.p; s.mesh_nrm = (const float4 *)c->mesh_nrm.p;
+    s.n_mesh = c->n_mesh; s.n_chunks = c->n_chunks;
+    for (int k = 0; k < 3; k++) { s.bmin[k] = c->bmin[k]; s.bmax[k] = c->bmax[k]; }
+    s.tri_p1 = (const float4 *)c->tri_p1.p; s.tri_e1 = (const float4 *)c->tri_e1.p;
+    s.tri_e2 = (const float4 *)c->tri_e2.p; s.tri_nrm = (const float4 *)c->tri_nrm.p;
+    s.n_tris = c->n_tris;
+    s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
+    s.mats = (const PtMaterial *)c->mats.p;
+    return s;
+}
+
+FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_mode)
+{
+    FrameParams f;
+    std::memset(&f, 0, sizeof f);
+    f.width = c->width; f.height = c->height;
+    for (int k = 0; k < 3; k++) f.cam[k] = c->cam[k];
+    for (int k = 0; k < 9; k++) f.iv[k] = c->iv[k];
+    f.max_bounces = c->max_bounces; f.debug_normal = c->debug_normal;
+    f.first_pass = first_pass; f.n_passes = n_passes; f.sum_mode = sum_mode;
+    f.accum = c->accum;
+    f.counters = (unsigned long long *)c->counters.p;
+    return f;
+}
+
+int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (first_pass < 0 || n_passes < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, n_passes);
+    Bind b(c); HIPCHK(c, b.e);
+    const int tiles = (c->width / 8) * (c->height / 8);
+    SceneView sv = scene_view(c);
+    FrameParams fp = frame_params(c, first_pass, n_passes, sum_mode);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(pt_trace_tiles<kSlots>, dim3(tiles), dim3(kWave), 0, c->stream, sv, fp);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_version(void) { return 1; }
+const char *pt_kernel_name(void) { return "pt_trace_tiles"; }
+
+const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_create(pt_ctx **out, int device)
+{
+    if (!out) return fail(nullptr, PT_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, PT_E_HIP, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, PT_E_INVALID, "device %d out of range [0,%d)", device, n);
+    pt_ctx *c = new pt_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        fail(nullptr, PT_E_HIP, "context setup failed: %s", hipGetErrorString(e));
+        delete c;
+        return PT_E_HIP;
+    }
+    c->stream = c->own_stream;
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    if ((e = c->counters.upload(zero, sizeof zero, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+        fail(nullptr, PT_E_HIP, "counter setup failed: %s", hipGetErrorString(e));
+        delete c;
+        return PT_E_HIP;
+    }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters}) b->release();
+    if (c->accum_own) (void)hipFree(c->accum_own);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pt_resize(pt_ctx *c, int width, int height)
+{
+    if (!c) return PT_E_INVALID;
+    if (width < 8 || height < 8) return fail(c, PT_E_INVALID, "image must be at least 8x8 (glDispatchCompute(W/8, H/8, 1))");
+    if ((long long)width * height > (1ll << 28)) return fail(c, PT_E_LIMIT, "image larger than 2^28 pixels");
+    Bind b(c); HIPCHK(c, b.e);
+    size_t bytes = (size_t)width * height * 4 * sizeof(float);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bytes > c->accum_own_bytes) {
+        if (c->accum_own) { HIPCHK(c, hipFree(c->accum_own)); c->accum_own = nullptr; c->accum_own_bytes = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->accum_own, bytes));
+        c->accum_own_bytes = bytes;
+    }
+    c->width = width; c->height = height;
+    c->accum = c->accum_own; c->accum_external = false;
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, bytes, c->stream));
+    return PT_OK;
+}
+
+int pt_set_accum_buffer(pt_ctx *c, void *dev, size_t bytes)
+{
+    if (!c) return PT_E_INVALID;
+    if (c->width < 8) return fail(c, PT_E_STATE, "call pt_resize first");
+    if (!dev) { c->accum = c->accum_own; c->accum_external = false; return PT_OK; }
+    size_t need = (size_t)c->width * c->height * 4 * sizeof(float);
+    if (bytes < need) return fail(c, PT_E_INVALID, "external accumulation buffer too small: %zu < %zu", bytes, need);
+    if (((uintptr_t)dev & 15u) != 0) return fail(c, PT_E_INVALID, "external accumulation buffer must be 16-byte aligned");
+    c->accum = (float *)dev; c->accum_external = true;
+    return PT_OK;
+}
+
+int pt_set_stream(pt_ctx *c, void *s)
+{
+    if (!c) return PT_E_INVALID;
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->timed = false;
+    return PT_OK;
+}
+
+int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes, int n_nodes)
+{
+    if (!c) return PT_E_INVALID;
+    if (n < 0 || (n > 0 && !tris)) return fail(c, PT_E_INVALID, "bad mesh triangle array");
+    if (n > 0 && (n_nodes < 1 || !nodes)) return fail(c, PT_E_INVALID, "a mesh needs nodes[0] (root AABB, rt.comp:213)");
+    if (n > (1 << 24)) return fail(c, PT_E_LIMIT, "more than 2^24 mesh triangles");
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int chunks = (n + kChunk - 1) / kChunk;
+    std::vector<float4> p1(n), e1(n), e2(n), nr(n);
+    // padded slots: p1 = e1 = e2 = 0 -> det = 0, inv = inf, t = inf*0 = NaN -> `t > HIT_LIMIT` is false: never hits
+    std::vector<float> soa((size_t)chunks * 9 * kChunk, 0.0f);
+    uint32_t maxm = 0;
+    for (int i = 0; i < n; i++) {
+        tri_precompute(tris[i], p1[i], e1[i], e2[i], nr[i]);
+        if (tris[i].materialIndex > maxm) maxm = tris[i].materialIndex;
+        const int chunk = i / kChunk, r = i % kChunk, lane = r / kSlots, slot = r % kSlots;
+        float *base = soa.data() + (size_t)chunk * 9 * kChunk + slot * kWave + lane;
+        const float comp[9] = {p1[i].x, p1[i].y, p1[i].z, e1[i].x, e1[i].y, e1[i].z, e2[i].x, e2[i].y, e2[i].z};
+        for (int k = 0; k < 9; k++) base[(size_t)k * kChunk] = comp[k];
+    }
+    HIPCHK(c, c->mesh_soa.upload(soa.data(), soa.size() * sizeof(float), c->stream));
+    HIPCHK(c, c->mesh_p1.upload(p1.data(), p1.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->mesh_e1.upload(e1.data(), e1.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->mesh_e2.upload(e2.data(), e2.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->mesh_nrm.upload(nr.data(), nr.size() * sizeof(float4), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));    // host staging vectors die here
+    c->n_mesh = n; c->n_chunks = chunks; c->max_mat_mesh = maxm;
+    for (int k = 0; k < 3; k++) { c->bmin[k] = n ? nodes[0].boundsMin[k] : 0.0f; c->bmax[k] = n ? nodes[0].boundsMax[k] : 0.0f; }
+    c->have_mesh = true;
+    return PT_OK;
+}
+
+int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSphere *sph, int n_sph, const PtTriangle *tris, int n_tris)
+{
+    if (!c) return PT_E_INVALID;
+    if (n_mats < 0 || n_sph < 0 || n_tris < 0 || (n_mats && !mats) || (n_sph && !sph) || (n_tris && !tris))
+        return fail(c, PT_E_INVALID, "bad scene arrays");
+    if (n_sph > (1 << 20) || n_tris > (1 << 20) || n_mats > (1 << 20)) return fail(c, PT_E_LIMIT, "more than 2^20 scene records");
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> p1(n_tris), e1(n_tris), e2(n_tris), nr(n_tris), sp(n_sph);
+    std::vector<uint32_t> sm(n_sph);
+    uint32_t maxm = 0;
+    for (int i = 0; i < n_tris; i++) { tri_precompute(tris[i], p1[i], e1[i], e2[i], nr[i]); if (tris[i].materialIndex > maxm) maxm = tris[i].materialIndex; }
+    for (int i = 0; i < n_sph; i++) {
+        sp[i] = make_float4(sph[i].position[0], sph[i].position[1], sph[i].position[2], sph[i].radius);
+        sm[i] = sph[i].materialIndex; if (sm[i] > maxm) maxm = sm[i];
+    }
+    HIPCHK(c, c->tri_p1.upload(p1.data(), p1.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->tri_e1.upload(e1.data(), e1.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->tri_e2.upload(e2.data(), e2.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->tri_nrm.upload(nr.data(), nr.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->sph.upload(sp.data(), sp.size() * sizeof(float4), c->stream));
+    HIPCHK(c, c->sph_mat.upload(sm.data(), sm.size() * sizeof(uint32_t), c->stream));
+    HIPCHK(c, c->mats.upload(mats, (size_t)n_mats * sizeof(PtMaterial), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_tris = n_tris; c->n_sph = n_sph; c->n_mats = n_mats; c->max_mat_scene = maxm;
+    c->have_scene = true;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_ctx *c, const float pos[3], const float iv[16])
+{
+    if (!c || !pos || !iv) return PT_E_INVALID;
+    for (int k = 0; k < 3; k++) c->cam[k] = pos[k];
+    for (int col = 0; col < 3; col++)
+        for (int r = 0; r < 3; r++) c->iv[col * 3 + r] = iv[col * 4 + r];
+    c->have_camera = true;
+    return PT_OK;
+}
+
+int pt_set_debug_normal(pt_ctx *c, int enabled) { if (!c) return PT_E_INVALID; c->debug_normal = enabled ? 1 : 0; return PT_OK; }
+
+int pt_set_max_bounces(pt_ctx *c, int n)
+{
+    if (!c) return PT_E_INVALID;
+    if (n < 1 || n > 4096) return fail(c, PT_E_INVALID, "max_bounces %d outside [1,4096]", n);
+    c->max_bounces = n;
+    return PT_OK;
+}
+
+int pt_render_pass(pt_ctx *c, int pass)
+{
+    if (!c) return PT_E_INVALID;
+    if (pass < 1) return fail(c, PT_E_INVALID, "currAccumPass starts at 1 (src/Main.cpp:144); pass 0 would divide by zero");
+    return launch_trace(c, pass, 1, 0);
+}
+
+int pt_render(pt_ctx *c, int first_pass, int n_passes)
+{
+    if (!c) return PT_E_INVALID;
+    if (first_pass < 1) return fail(c, PT_E_INVALID, "currAccumPass starts at 1 (src/Main.cpp:144)");
+    return launch_trace(c, first_pass, n_passes, 0);
+}
+
+int pt_render_sum(pt_ctx *c, int first_pass, int n_passes) { if (!c) return PT_E_INVALID; return launch_trace(c, first_pass, n_passes, 1); }
+
+int pt_scale_accum(pt_ctx *c, float scale, int set_alpha_one)
+{
+    if (!c) return PT_E_INVALID;
+    if (!c->accum) return fail(c, PT_E_STATE, "image size not set (pt_resize)");
+    Bind b(c); HIPCHK(c, b.e);
+    size_t n = (size_t)c->width * c->height;
+    hipLaunchKernelGGL(pt_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (float4 *)c->accum, n, scale, set_alpha_one);
+    HIPCHK(c, hipGetLastError());
+    return PT_OK;
+}
+
+int pt_reset(pt_ctx *c)
+{
+    if (!c) return PT_E_INVALID;
+    if (!c->accum) return fail(c, PT_E_STATE, "image size not set (pt_resize)");
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, (size_t)c->width * c->height * 4 * sizeof(float), c->stream));
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx *c)
+{
+    if (!c) return PT_E_INVALID;
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_read_accum(pt_ctx *c, float *rgba, size_t bytes)
+{
+    if (!c || !rgba) return PT_E_INVALID;
+    if (!c->accum) return fail(c, PT_E_STATE, "image size not set (pt_resize)");
+    size_t need = (size_t)c->width * c->height * 4 * sizeof(float);
+    if (bytes < need) return fail(c, PT_E_INVALID, "host buffer too small: %zu < %zu", bytes, need);
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipMemcpyAsync(rgba, c->accum, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+void *pt_accum_device_ptr(pt_ctx *c) { return c ? (void *)c->accum : nullptr; }
+
+int pt_read_primary_hits(pt_ctx *c, int pass, int32_t *ids, float *t, float *dirs, uint32_t *rng)
+{
+    int rc = check_ready(c);
+    if (rc) return rc;
+    Bind b(c); HIPCHK(c, b.e);
+    const size_t n = (size_t)c->width * c->height;
+    int32_t *d_ids = nullptr; float *d_t = nullptr, *d_dirs = nullptr; uint32_t *d_rng = nullptr;
+    auto cleanup = [&]() { if (d_ids) (void)hipFree(d_ids); if (d_t) (void)hipFree(d_t); if (d_dirs) (void)hipFree(d_dirs); if (d_rng) (void)hipFree(d_rng); };
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, PT_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); } } while (0)
+    if (ids) { TRY(hipMalloc((void **)&d_ids, n * 4)); TRY(hipMemsetAsync(d_ids, 0xff, n * 4, c->stream)); }
+    if (t) { TRY(hipMalloc((void **)&d_t, n * 4)); TRY(hipMemsetAsync(d_t, 0, n * 4, c->stream)); }
+    if (dirs) { TRY(hipMalloc((void **)&d_dirs, n * 12)); TRY(hipMemsetAsync(d_dirs, 0, n * 12, c->stream)); }
+    if (rng) { TRY(hipMalloc((void **)&d_rng, n * 4)); TRY(hipMemsetAsync(d_rng, 0, n * 4, c->stream)); }
+    SceneView sv = scene_view(c);
+    FrameParams fp = frame_params(c, pass, 1, 0);
+    fp.counters = nullptr;
+    fp.out_ids = d_ids; fp.out_t = d_t; fp.out_dirs = d_dirs; fp.out_rng = d_rng;
+    const int tiles = (c->width / 8) * (c->height / 8);
+    hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3(tiles), dim3(kWave), 0, c->stream, sv, fp);
+    TRY(hipGetLastError());
+    if (ids) TRY(hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (t) TRY(hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (dirs) TRY(hipMemcpyAsync(dirs, d_dirs, n * 12, hipMemcpyDeviceToHost, c->stream));
+    if (rng) TRY(hipMemcpyAsync(rng, d_rng, n * 4, hipMemcpyDeviceToHost, c->stream));
+    TRY(hipStreamSynchronize(c->stream));
+#undef TRY
+    cleanup();
+    return PT_OK;
+}
+
+int pt_get_counters(pt_ctx *c, PtCounters *out)
+{
+    if (!c || !out) return PT_E_INVALID;
+    Bind b(c); HIPCHK(c, b.e);
+    unsigned long long v[4];
+    HIPCHK(c, hipMemcpyAsync(v, c->counters.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3];
+    return PT_OK;
+}
+
+int pt_reset_counters(pt_ctx *c)
+{
+    if (!c) return PT_E_INVALID;
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    return PT_OK;
+}
+
+int pt_last_render_ms(pt_ctx *c, float *ms)
+{
+    if (!c || !ms) return PT_E_INVALID;
+    if (!c->timed) return fail(c, PT_E_STATE, "no render has been launched on this stream yet");
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+// pt_kernels.hpp — HIP kernels of the path-tracing hot path for gfx950 (MI355X, wave64).
+//
+// Structure ("triangle-stationary wave"): one wave64 owns an 8x8 pixel tile for all requested
+// passes.  Pixel work (ray generation, RNG, shading, accumulation) runs one pixel per lane.  The
+// >99 % hot loop -- brute-force ray/triangle tests against the mesh (rt.comp:213-218) -- runs the
+// other way round: every lane keeps SLOTS mesh triangles in VGPRs for the whole kernel (loaded once,
+// coalesced, from a slot-major SoA image), and the rays that passed the root-AABB gate are taken one
+// at a time from the wave's ballot mask, broadcast to all lanes through SGPRs (v_readlane), tested
+// against 64*SLOTS triangles at once, and reduced with a DPP min + ballot.  Cost is proportional to the
+// number of rays that need the mesh, independent of how they are scattered over lanes, so the
+// divergence that a pixel-per-lane loop suffers after the first bounce does not exist here.
+// Closest-hit ties resolve to the lowest primitive index exactly like the shader's in-order strict
+// `<` scan: lane l holds triangles [l*SLOTS, (l+1)*SLOTS), so "lowest lane among equal t" is
+// "lowest index".
+#pragma once
+#include "pt_math.hpp"
+#include "../../include/pt_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace pt {
+
+constexpr int kWave = 64;
+constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
+constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
+
+struct SceneView {
+    const float *mesh_soa;    // [n_chunks][9][kChunk]; component c of triangle (chunk, lane, slot) at c*kChunk + slot*64 + lane
+    const float4 *mesh_p1;    // per mesh triangle: xyz = p1, w = bits(materialIndex)
+    const float4 *mesh_e1;    // xyz = p2 - p1
+    const float4 *mesh_e2;    // xyz = p3 - p1
+    const float4 *mesh_nrm;   // xyz = normalize(cross(e2, e1))   (rt.comp:171)
+    int n_mesh, n_chunks;
+    float bmin[3], bmax[3];   // nodes[0] (rt.comp:213)
+    const float4 *tri_p1, *tri_e1, *tri_e2, *tri_nrm;   // scene triangles (SSBO 5), same encoding
+    int n_tris;
+    const float4 *sph;        // xyz = centre, w = radius (SSBO 4)
+    const uint32_t *sph_mat;
+    int n_sph;
+    const PtMaterial *mats;   // SSBO 3
+};
+
+struct FrameParams {
+    int width, height;
+    float cam[3];
+    float iv[9];              // inverseView columns 0,1,2 (xyz each); column 3 and row w are never read (rt.comp:333)
+    int max_bounces, debug_normal;
+    int first_pass, n_passes;
+    int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
+    float *accum;             // RGBA32F, row 0 = bottom
+    unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests
+    // primary-hit probe outputs (test-only kernel)
+    int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
+};
+
+template <int SLOTS>
+struct TriRegs { float p1x[SLOTS], p1y[SLOTS], p1z[SLOTS], e1x[SLOTS], e1y[SLOTS], e1z[SLOTS], e2x[SLOTS], e2y[SLOTS], e2z[SLOTS]; };
+
+template <int SLOTS>
+__device__ __forceinline__ void load_chunk(TriRegs<SLOTS> &T, const float *__restrict__ soa, int chunk, int lane)
+{
+    const float *b = soa + (size_t)chunk * 9 * (kWave * SLOTS) + lane;
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        T.p1x[s] = b[0 * kWave * SLOTS + s * kWave]; T.p1y[s] = b[1 * kWave * SLOTS + s * kWave]; T.p1z[s] = b[2 * kWave * SLOTS + s * kWave];
+        T.e1x[s] = b[3 * kWave * SLOTS + s * kWave]; T.e1y[s] = b[4 * kWave * SLOTS + s * kWave]; T.e1z[s] = b[5 * kWave * SLOTS + s * kWave];
+        T.e2x[s] = b[6 * kWave * SLOTS + s * kWave]; T.e2y[s] = b[7 * kWave * SLOTS + s * kWave]; T.e2z[s] = b[8 * kWave * SLOTS + s * kWave];
+    }
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// wave64 minimum through DPP (no LDS): prefix-min inside each row of 16, then row broadcasts; the
+// result is valid in lane 63.  min is idempotent, so full row/bank masks with old = self are safe.
+__device__ __forceinline__ float wave_min_to_lane63(float v)
+{
+#define PT_DPP_MIN(ctrl, rmask)                                                                                         \
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xf, false)))
+    PT_DPP_MIN(0x111, 0xf);  // row_shr:1
+    PT_DPP_MIN(0x112, 0xf);  // row_shr:2
+    PT_DPP_MIN(0x114, 0xf);  // row_shr:4
+    PT_DPP_MIN(0x118, 0xf);  // row_shr:8
+    PT_DPP_MIN(0x142, 0xa);  // row_bcast:15 -> rows 1,3
+    PT_DPP_MIN(0x143, 0xc);  // row_bcast:31 -> rows 2,3
+#undef PT_DPP_MIN
+    return v;
+}
+
+// Closest mesh hit for every lane whose bit is set in `mask` (wave-uniform).  best_t/best_id are the
+// per-pixel-lane results (kInfinity / -1 when nothing is hit).  rt.comp:213-218.
+template <int SLOTS>
+__device__ __forceinline__ void mesh_closest(const SceneView &sc, TriRegs<SLOTS> &T, int lane, unsigned long long mask,
+                                             v3 o, v3 d, float &best_t, int &best_id)
+{
+    const bool resident = sc.n_chunks == 1;      // single chunk: registers were filled once at kernel start
+    for (int chunk = 0; chunk < sc.n_chunks; chunk++) {
+        if (!resident) load_chunk<SLOTS>(T, sc.mesh_soa, chunk, lane);
+        unsigned long long m = mask;
+        while (m) {
+            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+            m &= m - 1;
+            // broadcast the ray through SGPRs
+            const v3 ro = V(readlane_f(o.x, src), readlane_f(o.y, src), readlane_f(o.z, src));
+            const v3 rd = V(readlane_f(d.x, src), readlane_f(d.y, src), readlane_f(d.z, src));
+            float lt = kInfinity;
+            int ls = 0;
+#pragma unroll
+            for (int s = 0; s < SLOTS; s++) {
+                float t, det;
+                bool has = hit_triangle(V(T.p1x[s], T.p1y[s], T.p1z[s]), V(T.e1x[s], T.e1y[s], T.e1z[s]), V(T.e2x[s], T.e2y[s], T.e2z[s]),
+                                        ro, rd, t, det);
+                if (has && t < lt) { lt = t; ls = s; }
+                // keep the slots sequential: interleaving 11 independent tests costs ~20 live VGPRs each
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float tmin = readlane_f(wave_min_to_lane63(lt), 63);
+            if (tmin < kInfinity) {
+                const unsigned long long winners = __ballot(lt == tmin);
+                const int wl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(winners));
+                const int slot = __builtin_amdgcn_readlane(ls, wl);
+                const int id = chunk * (kWave * SLOTS) + wl * SLOTS + slot;
+                const float cur = readlane_f(best_t, src);
+                if (tmin < cur && lane == src) { best_t = tmin; best_id = id; }
+            }
+        }
+    }
+}
+
+struct Hit { int id; float t; bool front; v3 normal; uint32_t mat; };
+
+// CalculateRay (rt.comp:204-232) for the pixel of this lane; `alive` lanes take part, the mesh part is
+// wave-cooperative.  Canonical ids: mesh i | n_mesh + i | n_mesh + n_tris + i | -1.
+template <int SLOTS>
+__device__ __forceinline__ Hit calculate_ray(const SceneView &sc, TriRegs<SLOTS> &T, int lane, bool alive, v3 o, v3 d,
+                                             unsigned &n_seg, unsigned &n_mesh_seg)
+{
+    Hit h;
+    h.id = -1; h.t = kInfinity; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
+    bool gate = false;
+    if (alive && sc.n_mesh > 0)
+        gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), o, d);
+    const unsigned long long gate_mask = __ballot(gate);
+    n_seg += __popcll(__ballot(alive));
+    n_mesh_seg += __popcll(gate_mask);
+    if (gate_mask) mesh_closest<SLOTS>(sc, T, lane, gate_mask, o, d, h.t, h.id);
+    if (!alive) return h;
+
+    float win_det = 0.0f;
+    int win_tri = -1;   // scene-triangle index of the current winner, if it is one
+    for (int i = 0; i < sc.n_tris; i++) {
+        float4 p1 = sc.tri_p1[i], e1 = sc.tri_e1[i], e2 = sc.tri_e2[i];
+        float t, det;
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        if (has && t < h.t) { h.t = t; h.id = sc.n_mesh + i; win_tri = i; win_det = det; }
+    }
+    bool sph_front = false;
+    int win_sph = -1;
+    for (int i = 0; i < sc.n_sph; i++) {
+        float4 s = sc.sph[i];
+        float t; bool front;
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        if (has && t < h.t) { h.t = t; h.id = sc.n_mesh + sc.n_tris + i; win_sph = i; sph_front = front; }
+    }
+    if (h.id < 0) return h;
+    if (win_sph >= 0) {
+        float4 s = sc.sph[win_sph];
+        v3 point = o + d * h.t;                                         // rt.comp:144
+        v3 n = normalize(point - V(s.x, s.y, s.z));
+        h.front = sph_front;
+        h.normal = sph_front ? n : -n;                                  // rt.comp:147
+        h.mat = sc.sph_mat[win_sph];
+    } else {
+        float4 p1, nr;
+        if (win_tri >= 0) {
+            p1 = sc.tri_p1[win_tri]; nr = sc.tri_nrm[win_tri];
+        } else {
+            // mesh winner: recompute det with the same operations the test used
+            p1 = sc.mesh_p1[h.id]; nr = sc.mesh_nrm[h.id];
+            float4 e1 = sc.mesh_e1[h.id], e2 = sc.mesh_e2[h.id];
+            float t;
+            hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, win_det);
+        }
+        v3 n = V(nr.x, nr.y, nr.z);
+        h.front = !(win_det < 0.0f);                                    // rt.comp:174
+        h.normal = win_det < 0.0f ? n : -n;                             // rt.comp:177
+        h.mat = __float_as_uint(p1.w);
+    }
+    return h;
+}
+
+// rt.comp:326-333.  Returns the rng state after the six jitter draws.
+__device__ __forceinline__ uint32_t primary_ray(const FrameParams &fp, int x, int y, int pass, v3 &o, v3 &d)
+{
+    const float W = (float)fp.width, H = (float)fp.height;
+    const float vx = (float)x / W, vy = (float)y / H;
+    const float px = ((vx - 0.5f) * W) / H;            // rt.comp:14,17
+    const float py = vy - 0.5f;
+    uint32_t state = (uint32_t)pass * pixel_index(x, y, W, H);          // rt.comp:327
+    // `RandomDirection(s) * 0.00025` (rt.comp:332): the reference's compiler folds the constant into the
+    // normalize as (v * 0.00025) * (1/sqrt(dot(v,v)))
+    float gx = random_value_nd(state), gy = random_value_nd(state), gz = random_value_nd(state);
+    v3 g = V(gx, gy, gz);
+    float gr = 1.0f / sqrtf(dot(g, g));
+    v3 jit = (g * 0.00025f) * gr;
+    const float X = -px + jit.x, Y = py + jit.y;
+    const float *m = fp.iv;   // c0 = m[0..2], c1 = m[3..5], c2 = m[6..8]
+    // mat4 * vec4(X, Y, 1, 0) -> (c0*X + c2) + c1*Y
+    d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
+    o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
+    return state;
+}
+
+// RayTrace (rt.comp:256-323) for the pixel of this lane; all 64 lanes must call it together.
+template <int SLOTS>
+__device__ __forceinline__ v3 ray_trace(const SceneView &sc, const FrameParams &fp, TriRegs<SLOTS> &T, int lane, v3 o, v3 d,
+                                        uint32_t &state, unsigned &n_seg, unsigned &n_mesh_seg)
+{
+    v3 ray_color = V(1, 1, 1), incoming = V(0, 0, 0), emitted = V(0, 0, 0);
+    const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;       // rt.comp:23
+    int bounces = 0;
+    bool alive = true;
+    v3 result = V(0, 0, 0);
+    bool returned_normal = false;
+    for (int i = 0; i < max_bounces; i++) {
+        if (!__any(alive)) break;
+        Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, o, d, n_seg, n_mesh_seg);
+        if (!alive) {
+            // finished path: this lane only helps the wave-cooperative mesh test above
+        } else if (h.id >= 0 && h.t < kInfinity && fp.debug_normal) {
+            result = h.normal; returned_normal = true; alive = false;                                        // rt.comp:274
+        } else if (h.id >= 0 && h.t < kInfinity) {
+            bounces++;
+            const PtMaterial *m = &sc.mats[h.mat];
+            const float m_ior = m->ior, m_smooth = m->smoothness, m_spec_smooth = m->specularSmoothness;
+            o = o + d * h.t;                                            // hitPoint (rt.comp:175 / :144)
+            const float ior = h.front ? (1.0f / m_ior) : m_ior;
+            const bool is_spec = m->specularChance > random_value(state);
+            const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, d, 1.0f - m->refractionAmount);
+            const bool is_refr = fres < random_value(state);
+            const v3 hemi = random_in_hemisphere(h.normal, state);
+            const v3 a = mix3(hemi, reflect3(d, h.normal), is_spec ? m_spec_smooth : m_smooth);
+            const v3 b = mix3(-hemi, refract3(d, h.normal, ior), m_smooth);
+            d = normalize(select3(is_refr, b, a));
+            o = o + d * 0.0002f;                                        // rt.comp:305
+            const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
+            const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
+            emitted = emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
+            ray_color = ray_color * select3(is_refr, base, select3(is_spec, spec, base));
+            incoming = incoming + emitted * ray_color;
+        } else {
+            bounces++;
+            emitted = emitted + V(0.5f, 0.5f, 0.5f);                    // skyColor * skyIntensity (rt.comp:315)
+            incoming = incoming + emitted * ray_color;                 // rayColor *= vec3(1) is exact
+            alive = false;                                              // break (rt.comp:318)
+        }
+    }
+    if (returned_normal) return result;
+    const float nb = (float)bounces;
+    return V(incoming.x / nb, incoming.y / nb, incoming.z / nb);      // rt.comp:322
+}
+
+// ------------------------------------------------------------------------------------------------
+// The hot kernel: grid = (W/8)*(H/8) single-wave workgroups, like glDispatchCompute(W/8, H/8, 1).
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave, 3) pt_trace_tiles(SceneView sc, FrameParams fp)
+{
+    const int lane = threadIdx.x;
+    const int tiles_x = fp.width >> 3;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+
+    TriRegs<SLOTS> T;
+    if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
+
+    float4 *px = reinterpret_cast<float4 *>(fp.accum) + ((size_t)y * fp.width + x);
+    const float4 prev = *px;
+    v3 acc = V(prev.x, prev.y, prev.z);
+    unsigned n_seg = 0, n_mesh_seg = 0;
+    for (int k = 0; k < fp.n_passes; k++) {
+        const int pass = fp.first_pass + k;
+        v3 o, d;
+        uint32_t state = primary_ray(fp, x, y, pass, o, d);
+        const v3 c = ray_trace<SLOTS>(sc, fp, T, lane, o, d, state, n_seg, n_mesh_seg);
+        if (fp.sum_mode) {
+            acc = acc + c;
+        } else {
+            const float t = 1.0f / (float)pass;                         // rt.comp:337
+            acc = mix3(acc, c, t);
+        }
+    }
+    *px = make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? prev.w + (float)fp.n_passes : 1.0f);
+    if (lane == 0 && fp.counters) {
+        atomicAdd(&fp.counters[0], (unsigned long long)kWave * fp.n_passes);
+        atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
+        atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
+        atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
+    }
+}
+
+// Test-only probe: primary ray + CalculateRay per pixel (pt_read_primary_hits).
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave, 3) pt_primary_hits(SceneView sc, FrameParams fp)
+{
+    const int lane = threadIdx.x;
+    const int tiles_x = fp.width >> 3;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    TriRegs<SLOTS> T;
+    if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
+    v3 o, d;
+    uint32_t state = primary_ray(fp, x, y, fp.first_pass, o, d);
+    unsigned a = 0, b = 0;
+    Hit h = calculate_ray<SLOTS>(sc, T, lane, true, o, d, a, b);
+    const size_t i = (size_t)y * fp.width + x;
+    if (fp.out_ids) fp.out_ids[i] = h.id;
+    if (fp.out_t) fp.out_t[i] = h.t;
+    if (fp.out_dirs) { fp.out_dirs[3 * i] = d.x; fp.out_dirs[3 * i + 1] = d.y; fp.out_dirs[3 * i + 2] = d.z; }
+    if (fp.out_rng) fp.out_rng[i] = state;
+}
+
+__global__ void pt_scale_kernel(float4 *accum, size_t n, float scale, int set_alpha_one)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = accum[i];
+    v.x = v.x * scale; v.y = v.y * scale; v.z = v.z * scale;
+    if (set_alpha_one) v.w = 1.0f;
+    accum[i] = v;
+}
+
+}  // namespace pt

@@ -1,0 +1,231 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (a) the committed fixtures from the
+reference shader under llvmpipe and (b) the oracle on the same inputs.  Bar: bit-exact everywhere
+(the path is float32 with a pinned operation order); the only toleranced test is the multi-GPU sum
+mode, whose summation order differs from the reference's running mean by construction."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, SCENE_CAM, bits_equal, crc, n_diff_pixels
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from path_tracer_amd import capi as m
+    m.load()
+    return m
+
+
+def make(capi, sc, cam, W, H, bounces, debug_normal=False):
+    r = capi.Renderer(W, H, device=0)
+    r.upload_scene(sc)
+    r.SetUniformCamera(cam)
+    r.SetUniform1i("maxBounces", bounces)
+    r.SetUniform1i("debugNormal", int(debug_normal))
+    return r
+
+
+@pytest.mark.parametrize("tag", ["default", "default_rot", "mixed"])
+@pytest.mark.parametrize("size", [(64, 40), (640, 360), (1920, 1080)])
+@pytest.mark.parametrize("p", [1, 7])
+def test_primary_hits_vs_reference_fixtures(capi, tag, size, p, meta, cameras, scenes):
+    W, H = size
+    r = make(capi, scenes[SCENE_CAM[tag][0]], cameras[SCENE_CAM[tag][1]], W, H, 3)
+    ids, t, dirs, st = r.read_primary_hits(p)
+    e = meta[f"primary_{tag}_{W}x{H}_p{p}"]
+    assert int((ids >= 0).sum()) == e["n_hits"]
+    assert crc(ids) == e["crc_ids"], "primary-hit primitive ids must be bit-exact"
+    assert crc(st) == e["crc_rng_after_jitter"], "hash RNG stream must be reproduced exactly"
+    assert crc(dirs) == e["crc_dirs"] and crc(t) == e["crc_t"]
+    r.close()
+
+
+def test_primary_hits_4k(capi, meta, cameras, scenes):
+    r = make(capi, scenes["default"], cameras["bench"], 3840, 2160, 3)
+    ids, t, dirs, st = r.read_primary_hits(1)
+    e = meta["primary_default_3840x2160_p1"]
+    assert crc(ids) == e["crc_ids"] and crc(st) == e["crc_rng_after_jitter"] and crc(dirs) == e["crc_dirs"] and crc(t) == e["crc_t"]
+    r.close()
+
+
+@pytest.mark.parametrize("tag", ["default", "mixed"])
+def test_debug_normal(capi, tag, meta, cameras, scenes):
+    g = np.load(os.path.join(GOLD, "debug_normal.npz"))
+    r = make(capi, scenes[SCENE_CAM[tag][0]], cameras[SCENE_CAM[tag][1]], 128, 72, 3, debug_normal=True)
+    r.render_pass(1)
+    assert n_diff_pixels(r.read_accum()[:, :, :3], g[f"{tag}_128x72"]) == 0
+    r.close()
+    r = make(capi, scenes[SCENE_CAM[tag][0]], cameras[SCENE_CAM[tag][1]], 640, 360, 3, debug_normal=True)
+    r.render_pass(1)
+    assert crc(r.read_accum()[:, :, :3]) == meta[f"normal_{tag}_640x360"]["crc_rgb"]
+    r.close()
+
+
+@pytest.mark.parametrize("tag,bounces", [("default", 3), ("default", 4), ("default", 8), ("default_rot", 4), ("mixed", 3), ("mixed", 16)])
+def test_running_mean_vs_reference_fixtures(capi, tag, bounces, cameras, scenes):
+    """one dispatch per pass, like the reference's frame loop (src/Main.cpp:144-150)"""
+    g = np.load(os.path.join(GOLD, "radiance_128x72.npz"))
+    r = make(capi, scenes[SCENE_CAM[tag][0]], cameras[SCENE_CAM[tag][1]], 128, 72, bounces)
+    for k in range(1, 17):
+        r.render_pass(k)
+        if k in (1, 2, 3, 4, 16):
+            acc = r.read_accum()
+            assert n_diff_pixels(acc[:, :, :3], g[f"{tag}_b{bounces}_128x72_mean{k}"]) == 0, f"running mean after pass {k}"
+            assert np.all(acc[:, :, 3] == 1.0)
+    r.close()
+
+
+def test_config1_640x360_16spp_4bounces(capi, meta, cameras, scenes):
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case, CRC of the reference image."""
+    r = make(capi, scenes["default"], cameras["bench"], 640, 360, 4)
+    r.render(1, 16)
+    acc = r.read_accum()
+    rows = np.load(os.path.join(GOLD, "radiance_c1_rows.npz"))
+    assert n_diff_pixels(acc[::8, :, :3], rows["mean16_rows8"]) == 0
+    assert crc(acc[:, :, :3]) == meta["radiance_default_b4_640x360"]["crc_mean16"]
+    r.close()
+
+
+def test_mixed_scene_16_bounces_640x360(capi, meta, cameras, scenes):
+    """BASELINE.json configs[4] scene (glass, specular, emissive; 145 spheres), 16 bounces."""
+    r = make(capi, scenes["mixed"], cameras["mixed"], 640, 360, 16)
+    r.render(1, 4)
+    assert crc(r.read_accum()[:, :, :3]) == meta["radiance_mixed_b16_640x360"]["crc_mean4"]
+    r.close()
+
+
+def test_batched_render_equals_per_pass_dispatches(capi, cameras, scenes):
+    a = make(capi, scenes["mixed"], cameras["mixed"], 128, 72, 8)
+    b = make(capi, scenes["mixed"], cameras["mixed"], 128, 72, 8)
+    a.render(1, 6)
+    for k in range(1, 7):
+        b.render_pass(k)
+    assert bits_equal(a.read_accum(), b.read_accum())
+    # resuming: passes 1..3 then 4..6
+    b.reset()
+    b.render(1, 3)
+    b.render(4, 3)
+    assert bits_equal(a.read_accum(), b.read_accum())
+    a.close(); b.close()
+
+
+def test_config2_1080p_64spp_8bounces_properties_and_oracle_windows(capi, cameras, scenes):
+    """BASELINE.json configs[1] at full size: determinism, pass-split invariance, and bit-exact windows
+    against the oracle (a full CPU render would take minutes)."""
+    import oracle_py as O
+    W, H, B, SPP = 1920, 1080, 8, 64
+    sc, cam = scenes["default"], cameras["bench"]
+    r = make(capi, sc, cam, W, H, B)
+    r.render(1, SPP)
+    full = r.read_accum()
+    c = r.counters()
+    assert c["samples"] == W * H * SPP and c["segments"] >= c["samples"] and 0 < c["mesh_segments"] < c["segments"]
+    r.reset()
+    r.render(1, 40)
+    r.render(41, 24)
+    assert crc(r.read_accum()) == crc(full), "pass-split invariance / determinism"
+    assert np.all(full[:, :, 3] == 1.0) and np.isfinite(full).all()
+    o = O.Oracle(sc, cam, W, H, B)
+    for (x0, y0, w, h) in ((900, 380, 96, 8), (0, 0, 64, 4), (1856, 1076, 64, 4), (1000, 300, 48, 8)):
+        want = o.render_region(1, SPP, x0, y0, w, h)
+        assert n_diff_pixels(full[y0:y0 + h, x0:x0 + w], want) == 0, (x0, y0)
+    r.close()
+
+
+def test_sum_mode_matches_mean_within_tolerance(capi, cameras, scenes):
+    """multi-GPU split building block: sum of per-pass radiance / spp vs the reference running mean."""
+    W, H, SPP = 128, 72, 32
+    a = make(capi, scenes["default"], cameras["bench"], W, H, 4)
+    a.render(1, SPP)
+    mean = a.read_accum()
+    a.reset()
+    a.render_sum(1, 20)
+    a.render_sum(21, 12)
+    s = a.read_accum()
+    assert np.all(s[:, :, 3] == SPP)
+    a.scale_accum(1.0 / SPP)
+    got = a.read_accum()
+    assert np.all(got[:, :, 3] == 1.0)
+    # tolerance: fp32 sum of 32 terms vs running mean; radiance values are O(1)
+    np.testing.assert_allclose(got[:, :, :3], mean[:, :, :3], rtol=1e-5, atol=1e-6)
+    a.close()
+
+
+def test_trailing_pixels_are_not_traced(capi, cameras, scenes):
+    """glDispatchCompute(W/8, H/8, 1) (src/Main.cpp:148): pixels beyond the last full 8x8 group stay untouched."""
+    import oracle_py as O
+    W, H = 70, 45
+    r = make(capi, scenes["default"], cameras["bench"], W, H, 3)
+    r.render(1, 2)
+    acc = r.read_accum()
+    assert np.all(acc[40:, :, :] == 0) and np.all(acc[:, 64:, :] == 0)
+    want = O.Oracle(scenes["default"], cameras["bench"], W, H, 3).render(1, 2)
+    assert n_diff_pixels(acc[:40, :64], want[:40, :64]) == 0
+    r.close()
+
+
+def test_multi_chunk_mesh_and_tie_breaking(capi, cameras):
+    """mesh larger than one register-resident chunk (704 tris) + duplicated triangles (equal t: lowest index wins)"""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    m = S.heightfield_mesh(24, 1)                      # 1152 triangles -> 2 chunks
+    dup = np.concatenate([m.tris, m.tris[:300]])      # exact duplicates later in the list must lose ties
+    mesh = S.Mesh(dup, S.Mesh.gen_bounding_box(dup), 1)
+    sc = S.default_scene(mesh)
+    cam = S.Camera(position=np.array([0.2, 1.6, 2.2], np.float32), yaw=95.0, pitch=35.0).UpdateView()
+    W, H = 128, 72
+    r = make(capi, sc, cam, W, H, 5)
+    ids, t, dirs, st = r.read_primary_hits(1)
+    o = O.Oracle(sc, cam, W, H, 5)
+    oi, ot, od, os_ = o.primary_hits(1)
+    assert (oi >= 0).sum() > 2000 and np.array_equal(ids, oi) and bits_equal(t, ot)
+    assert not np.any((ids >= 1152) & (ids < 1452)), "a duplicate won a tie against the earlier triangle"
+    r.render(1, 3)
+    assert n_diff_pixels(r.read_accum(), o.render(1, 3)) == 0
+    r.close()
+
+
+def test_no_mesh_spheres_only(capi, cameras):
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    sc = S.Scene(materials=S.default_materials())
+    sc.add_sphere((0.0, 0.5, 0.0), 0.5, 2)
+    sc.add_sphere((0.0, -100.0, 0.0), 100.0, 1)
+    sc.add_sphere((0.6, 0.3, 0.4), 0.3, 4)
+    cam = cameras["bench"]
+    r = make(capi, sc, cam, 64, 40, 8)
+    r.render(1, 4)
+    want = O.Oracle(sc, cam, 64, 40, 8).render(1, 4)
+    assert n_diff_pixels(r.read_accum(), want) == 0
+    r.close()
+
+
+def test_error_behaviour(capi, cameras, scenes):
+    L = capi.load()
+    h = C.c_void_p()
+    assert L.pt_create(C.byref(h), 0) == 0
+    assert L.pt_render_pass(h, 1) == capi.PT_E_STATE                      # nothing set up yet
+    assert b"pt_resize" in L.pt_last_error(h)
+    assert L.pt_resize(h, 4, 4) == capi.PT_E_INVALID
+    assert L.pt_resize(h, 64, 40) == 0
+    assert L.pt_render_pass(h, 1) == capi.PT_E_STATE
+    sc = scenes["default"]
+    mt, nd = np.ascontiguousarray(sc.mesh_tris), np.ascontiguousarray(sc.nodes)
+    assert L.pt_upload_mesh(h, mt.ctypes.data, len(mt), None, 0) == capi.PT_E_INVALID     # a mesh needs nodes[0]
+    assert L.pt_upload_mesh(h, mt.ctypes.data, len(mt), nd.ctypes.data, 1) == 0
+    ma = np.ascontiguousarray(sc.materials[:2])        # too few materials for the indices in use
+    tr = np.ascontiguousarray(sc.triangles)
+    assert L.pt_upload_scene(h, ma.ctypes.data, 2, None, 0, tr.ctypes.data, len(tr)) == 0
+    cam = cameras["bench"]
+    pos, iv = np.ascontiguousarray(cam.position, np.float32), cam.inv_view_flat()
+    fp = C.POINTER(C.c_float)
+    assert L.pt_set_camera(h, pos.ctypes.data_as(fp), iv.ctypes.data_as(fp)) == 0
+    assert L.pt_render_pass(h, 1) == capi.PT_E_INVALID and b"material" in L.pt_last_error(h)
+    assert L.pt_render_pass(h, 0) == capi.PT_E_INVALID                     # currAccumPass starts at 1
+    assert L.pt_set_max_bounces(h, 0) == capi.PT_E_INVALID
+    assert L.pt_create(C.byref(C.c_void_p()), 9999) == capi.PT_E_INVALID
+    L.pt_destroy(h)
