@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- samples/sec of the path-tracing hot path on N MI355X (BASELINE.json metric).
+
+A "step" is one full render of the workload BASELINE.json's metric is quoted on (configs[1]):
+default res/meshes scene (bunny1 656 tris + light + ground), 1920x1080, 64 spp per GPU, 8 bounces,
+bench camera (1.5, 0.4, 0) yaw 0 pitch 0.  Inputs (scene, camera) are resident in HBM before the timed
+region; the result stays in HBM on rank 0.
+
+N = 1: reference semantics exactly (running mean, rt.comp:337).  N > 1: samples-per-pixel split, one
+process per GPU (torch.distributed, backend nccl == RCCL over xGMI): rank g renders passes
+g*64+1 .. (g+1)*64 of the same image as a plain sum, the per-GPU RGBA32F buffers are summed onto rank 0
+with ONE reduce per render, rank 0 scales by 1/(64*N).  Per-GPU work is fixed -> weak scaling.
+
+Prints one JSON line on rank 0 (see the repo contract).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+W, H, SPP, BOUNCES = 1920, 1080, 64, 8
+FP32_VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md "Peak FP32 (vector)"
+# algorithmic FLOP per unit of work: Moeller-Trumbore test 52, slab test 27, shaded hit ~150
+FLOP_TRI, FLOP_AABB, FLOP_SPHERE, FLOP_SHADE = 52, 27, 35, 150
+
+
+def algorithmic_flops(c, sc):
+    """FLOP the reference algorithm needs for the work the kernel counted (padded register slots are NOT counted)."""
+    return (FLOP_TRI * (c["mesh_segments"] * len(sc.mesh_tris) + c["segments"] * len(sc.triangles))
+            + FLOP_SPHERE * c["segments"] * len(sc.spheres) + FLOP_AABB * c["segments"] + FLOP_SHADE * c["hits"])
+
+
+def cpu_baseline(sc, cam):
+    """The oracle (C restatement of the reference, oracle/pt_oracle.c) timed on this host's cores on a bounded
+    sample of the SAME workload: every 27th row of the 1080p frame (40 rows x 1920 px), 64 spp, 8 bounces."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    o = O.Oracle(sc, cam, W, H, BOUNCES)
+    rows = list(range(13, H, 27))
+    o.render_region(1, 1, 0, rows[0], W, 1)          # warm up (page in, thread pool)
+    t0 = time.perf_counter()
+    for y in rows:
+        o.render_region(1, SPP, 0, y, W, 1)
+    dt = time.perf_counter() - t0
+    n = len(rows) * W * SPP
+    return {"value": n / dt, "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
+            "sample": f"oracle/pt_oracle.c (OpenMP) on rows 13,40,..,{rows[-1]} of the 1920x1080 frame ({len(rows)} rows x {W} px), "
+                      f"{SPP} spp, {BOUNCES} bounces = {n} samples in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from path_tracer_amd import capi, scene as S
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: path_tracer_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    sc, cam = S.default_scene(), S.bench_camera()
+    r = capi.Renderer(W, H, device=local_rank)
+    r.upload_scene(sc)
+    r.SetUniformCamera(cam)
+    r.SetUniform1i("maxBounces", BOUNCES)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")      # device memory owned by torch: the reduce reads it
+    r.set_accum_buffer(accum.data_ptr(), accum.numel() * 4)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    first = rank * SPP + 1
+
+    def step():
+        accum.zero_()
+        if world == 1:
+            r.render(1, SPP)                                                 # reference semantics, bit-exact
+        else:
+            r.render_sum(first, SPP)
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)                  # the one exchange step (RCCL over xGMI)
+            if rank == 0:
+                r.scale_accum(1.0 / (SPP * world))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    r.reset_counters()
+    durs = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        # HIP events recorded on the launch stream around pt_trace_tiles (pt_last_render_ms waits for the kernel
+        # only: ~10 us of host time against a step of hundreds of ms)
+        durs.append(r.last_render_ms())
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    c = r.counters()
+    k_ms = float(np.mean(durs))
+    flops_per_launch = algorithmic_flops(c, sc) / a.steps
+    achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        total_samples = W * H * SPP * world * a.steps
+        out = {
+            "metric": "samples/sec (1080p, 8 bounces)", "value": total_samples / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: default res/meshes scene (bunny1 656 tris + 2 scene tris), 1920x1080, "
+                                   f"{SPP} spp per GPU, {BOUNCES} bounces, camera (1.5,0.4,0) yaw 0 pitch 0",
+                       "width": W, "height": H, "spp_per_gpu": SPP, "spp_total": SPP * world, "max_bounces": BOUNCES,
+                       "parallelism": "spp-split x%d + 1 RCCL reduce/render" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": capi.load().pt_kernel_name().decode(), "kernel_ms": k_ms,
+                         "algorithmic_flop_per_launch": flops_per_launch,
+                         "note": "FP32 vector peak (FMA-counted); the path's parity contract forbids FMA contraction, so "
+                                 "unfused mul/add can reach at most 50% of this peak (tools/valu_rate.hip)",
+                         "work_per_launch": {k: v / a.steps for k, v in c.items()}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, cam)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

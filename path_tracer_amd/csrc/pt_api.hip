@@ -182,7 +182,7 @@ int pt_create(pt_ctx **out, int device)
         return PT_E_HIP;
     }
     c->stream = c->own_stream;
-    unsigned long long zero[4] = {0, 0, 0, 0};
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((e = c->counters.upload(zero, sizeof zero, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "counter setup failed: %s", hipGetErrorString(e));
         delete c;
@@ -421,10 +421,10 @@ int pt_get_counters(pt_ctx *c, PtCounters *out)
 {
     if (!c || !out) return PT_E_INVALID;
     Bind b(c); HIPCHK(c, b.e);
-    unsigned long long v[4];
+    unsigned long long v[8];
     HIPCHK(c, hipMemcpyAsync(v, c->counters.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3];
+    out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3]; out->hits = v[4];
     return PT_OK;
 }
 
@@ -432,7 +432,7 @@ int pt_reset_counters(pt_ctx *c)
 {
     if (!c) return PT_E_INVALID;
     Bind b(c); HIPCHK(c, b.e);
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
     return PT_OK;
 }
 

@@ -48,7 +48,7 @@ struct FrameParams {
     int first_pass, n_passes;
     int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
     float *accum;             // RGBA32F, row 0 = bottom
-    unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests
+    unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
 };
@@ -213,7 +213,7 @@ __device__ __forceinline__ uint32_t primary_ray(const FrameParams &fp, int x, in
 // RayTrace (rt.comp:256-323) for the pixel of this lane; all 64 lanes must call it together.
 template <int SLOTS>
 __device__ __forceinline__ v3 ray_trace(const SceneView &sc, const FrameParams &fp, TriRegs<SLOTS> &T, int lane, v3 o, v3 d,
-                                        uint32_t &state, unsigned &n_seg, unsigned &n_mesh_seg)
+                                        uint32_t &state, unsigned &n_seg, unsigned &n_mesh_seg, unsigned &n_hits)
 {
     v3 ray_color = V(1, 1, 1), incoming = V(0, 0, 0), emitted = V(0, 0, 0);
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;       // rt.comp:23
@@ -224,6 +224,7 @@ __device__ __forceinline__ v3 ray_trace(const SceneView &sc, const FrameParams &
     for (int i = 0; i < max_bounces; i++) {
         if (!__any(alive)) break;
         Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, o, d, n_seg, n_mesh_seg);
+        n_hits += __popcll(__ballot(alive && h.id >= 0 && h.t < kInfinity));
         if (!alive) {
             // finished path: this lane only helps the wave-cooperative mesh test above
         } else if (h.id >= 0 && h.t < kInfinity && fp.debug_normal) {
@@ -275,12 +276,12 @@ __global__ void __launch_bounds__(kWave, 3) pt_trace_tiles(SceneView sc, FramePa
     float4 *px = reinterpret_cast<float4 *>(fp.accum) + ((size_t)y * fp.width + x);
     const float4 prev = *px;
     v3 acc = V(prev.x, prev.y, prev.z);
-    unsigned n_seg = 0, n_mesh_seg = 0;
+    unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0;
     for (int k = 0; k < fp.n_passes; k++) {
         const int pass = fp.first_pass + k;
         v3 o, d;
         uint32_t state = primary_ray(fp, x, y, pass, o, d);
-        const v3 c = ray_trace<SLOTS>(sc, fp, T, lane, o, d, state, n_seg, n_mesh_seg);
+        const v3 c = ray_trace<SLOTS>(sc, fp, T, lane, o, d, state, n_seg, n_mesh_seg, n_hits);
         if (fp.sum_mode) {
             acc = acc + c;
         } else {
@@ -294,6 +295,7 @@ __global__ void __launch_bounds__(kWave, 3) pt_trace_tiles(SceneView sc, FramePa
         atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
         atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
         atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
+        atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
     }
 }
 
