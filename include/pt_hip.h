@@ -86,8 +86,9 @@ int pt_set_max_bounces(pt_ctx *ctx, int max_bounces);
 /* One accumulation pass == SetUniform1i("currAccumPass", pass) + glDispatchCompute + glMemoryBarrier
  * (src/Main.cpp:144-150): accum = mix(accum, radiance(pass), 1/pass) (rt.comp:337-339). */
 int pt_render_pass(pt_ctx *ctx, int pass);
-/* Passes first_pass .. first_pass+n_passes-1 in order inside one launch; bit-identical to calling
- * pt_render_pass for each (the running mean is kept in registers and stored once). */
+/* Passes first_pass .. first_pass+n_passes-1: all samples are traced in one launch (per workspace batch)
+ * into a per-pass radiance workspace, then folded into the image in pass order; bit-identical to
+ * calling pt_render_pass for each pass. */
 int pt_render(pt_ctx *ctx, int first_pass, int n_passes);
 /* Multi-GPU sample split (no reference counterpart; BASELINE.json north_star): adds the plain sum of
  * the 1-spp radiances of the given passes to the accumulation image (alpha += n_passes) so that
@@ -111,9 +112,13 @@ int pt_read_primary_hits(pt_ctx *ctx, int pass, int32_t *ids, float *t, float *d
 /* --- measurement */
 int pt_get_counters(pt_ctx *ctx, PtCounters *out);
 int pt_reset_counters(pt_ctx *ctx);
-/* Device time (ms, HIP events on the context's stream) of the most recent pt_render / pt_render_pass /
- * pt_render_sum launch; waits for it to finish. */
-int pt_last_render_ms(pt_ctx *ctx, float *ms);
+/* Device time (ms, HIP events on the context's stream) spent in the dominant kernel (pt_trace_items) by
+ * the most recent pt_render / pt_render_pass / pt_render_sum call, summed over its launches (one per
+ * workspace batch; the count goes to *n_launches if not NULL); waits for them to finish. */
+int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
+/* Tuning knobs (0 = keep): passes per work item (default 4) and the byte limit of the per-pass radiance
+ * workspace [passes][H][W] float4 that bounds how many passes one launch covers (default 4 GiB). */
+int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes);
 /* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
 const char *pt_kernel_name(void);
 int pt_version(void);

@@ -21,7 +21,8 @@ SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
     "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
-    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_kernel_name", "pt_version",
+    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_kernel_name",
+    "pt_version",
 ]
 
 
@@ -73,7 +74,8 @@ def load():
     L.pt_read_primary_hits.argtypes = [vp, i32, vp, vp, vp, vp]
     L.pt_get_counters.argtypes = [vp, C.POINTER(PtCounters)]
     L.pt_reset_counters.argtypes = [vp]
-    L.pt_last_render_ms.argtypes = [vp, f32p]
+    L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
+    L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t]
     L.pt_kernel_name.restype = C.c_char_p
     L.pt_version.restype = i32
     _lib = L
@@ -173,5 +175,13 @@ class Renderer:
 
     def last_render_ms(self):
         ms = C.c_float()
-        self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms)))
+        self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms), None))
         return float(ms.value)
+
+    def last_render_launches(self):
+        ms, n = C.c_float(), C.c_int()
+        self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0):
+        self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes))

@@ -4,6 +4,7 @@
 // launches on the context's stream.  No CPU rendering path exists here.
 #include "pt_kernels.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,8 +42,11 @@ struct DevBuf {
 struct pt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    std::vector<hipEvent_t> ev;        // pairs (before, after) around every pt_trace_items launch of the last render
+    int n_timed = 0;
+    DevBuf radiance;                   // [batch passes][H][W] float4 workspace
+    size_t workspace_limit = (size_t)4 << 30;
+    int chunk_passes = 4;              // passes per work item
     std::string err;
 
     int width = 0, height = 0;
@@ -134,7 +138,11 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     for (int k = 0; k < 9; k++) f.iv[k] = c->iv[k];
     f.max_bounces = c->max_bounces; f.debug_normal = c->debug_normal;
     f.first_pass = first_pass; f.n_passes = n_passes; f.sum_mode = sum_mode;
+    f.chunk = c->chunk_passes;
+    f.traced_width = (c->width / 8) * 8; f.rows = (c->height / 8) * 8;
+    f.x_blocks = (f.traced_width + kWave - 1) / kWave;
     f.accum = c->accum;
+    f.radiance = (float4 *)c->radiance.p;
     f.counters = (unsigned long long *)c->counters.p;
     return f;
 }
@@ -145,14 +153,32 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     if (rc) return rc;
     if (first_pass < 0 || n_passes < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, n_passes);
     Bind b(c); HIPCHK(c, b.e);
-    const int tiles = (c->width / 8) * (c->height / 8);
+    const size_t plane_bytes = (size_t)c->width * c->height * sizeof(float4);
+    const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, c->workspace_limit / plane_bytes));
+    if (c->radiance.bytes < plane_bytes * batch) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->radiance.release();
+        HIPCHK(c, hipMalloc(&c->radiance.p, plane_bytes * batch));
+        c->radiance.bytes = plane_bytes * batch;
+    }
+    const int n_batches = (n_passes + batch - 1) / batch;
+    while ((int)c->ev.size() < 2 * n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev.push_back(e); }
     SceneView sv = scene_view(c);
-    FrameParams fp = frame_params(c, first_pass, n_passes, sum_mode);
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(pt_trace_tiles<kSlots>, dim3(tiles), dim3(kWave), 0, c->stream, sv, fp);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    c->n_timed = 0;
+    for (int bi = 0; bi < n_batches; bi++) {
+        const int p0 = first_pass + bi * batch, np = std::min(batch, n_passes - bi * batch);
+        FrameParams fp = frame_params(c, p0, np, sum_mode);
+        const int chunks = (np + fp.chunk - 1) / fp.chunk;
+        const long long items = (long long)fp.x_blocks * fp.rows * chunks;
+        if (items > 0x7fffffffll) return fail(c, PT_E_LIMIT, "too many work items in one batch (%lld); lower the workspace limit", items);
+        HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
+        hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3((unsigned)items), dim3(kWave), 0, c->stream, sv, fp);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
+        hipLaunchKernelGGL(pt_accumulate, dim3((fp.traced_width + 255) / 256, fp.rows), dim3(256), 0, c->stream, fp);
+        HIPCHK(c, hipGetLastError());
+        c->n_timed = bi + 1;
+    }
     return PT_OK;
 }
 
@@ -161,7 +187,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
 extern "C" {
 
 int pt_version(void) { return 1; }
-const char *pt_kernel_name(void) { return "pt_trace_tiles"; }
+const char *pt_kernel_name(void) { return "pt_trace_items"; }
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -175,8 +201,7 @@ int pt_create(pt_ctx **out, int device)
     if (device < 0 || device >= n) return fail(nullptr, PT_E_INVALID, "device %d out of range [0,%d)", device, n);
     pt_ctx *c = new pt_ctx();
     c->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "context setup failed: %s", hipGetErrorString(e));
         delete c;
         return PT_E_HIP;
@@ -200,8 +225,8 @@ void pt_destroy(pt_ctx *c)
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
                       &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    c->radiance.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -243,7 +268,7 @@ int pt_set_stream(pt_ctx *c, void *s)
     Bind b(c); HIPCHK(c, b.e);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
-    c->timed = false;
+    c->n_timed = 0;
     return PT_OK;
 }
 
@@ -404,8 +429,7 @@ int pt_read_primary_hits(pt_ctx *c, int pass, int32_t *ids, float *t, float *dir
     FrameParams fp = frame_params(c, pass, 1, 0);
     fp.counters = nullptr;
     fp.out_ids = d_ids; fp.out_t = d_t; fp.out_dirs = d_dirs; fp.out_rng = d_rng;
-    const int tiles = (c->width / 8) * (c->height / 8);
-    hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3(tiles), dim3(kWave), 0, c->stream, sv, fp);
+    hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
     TRY(hipGetLastError());
     if (ids) TRY(hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (t) TRY(hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -436,13 +460,29 @@ int pt_reset_counters(pt_ctx *c)
     return PT_OK;
 }
 
-int pt_last_render_ms(pt_ctx *c, float *ms)
+int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
 {
     if (!c || !ms) return PT_E_INVALID;
-    if (!c->timed) return fail(c, PT_E_STATE, "no render has been launched on this stream yet");
+    if (c->n_timed < 1) return fail(c, PT_E_STATE, "no render has been launched on this stream yet");
     Bind b(c); HIPCHK(c, b.e);
-    HIPCHK(c, hipEventSynchronize(c->ev1));
-    HIPCHK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    float total = 0.0f;
+    for (int i = 0; i < c->n_timed; i++) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventSynchronize(c->ev[2 * i + 1]));
+        HIPCHK(c, hipEventElapsedTime(&t, c->ev[2 * i], c->ev[2 * i + 1]));
+        total += t;
+    }
+    *ms = total;
+    if (n_launches) *n_launches = c->n_timed;
+    return PT_OK;
+}
+
+int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes)
+{
+    if (!c) return PT_E_INVALID;
+    if (passes_per_item < 0 || passes_per_item > 4096) return fail(c, PT_E_INVALID, "passes_per_item outside [1,4096]");
+    if (passes_per_item) c->chunk_passes = passes_per_item;
+    if (workspace_limit_bytes) c->workspace_limit = workspace_limit_bytes;
     return PT_OK;
 }
 

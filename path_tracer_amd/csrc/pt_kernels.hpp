@@ -1,7 +1,7 @@
 // pt_kernels.hpp — HIP kernels of the path-tracing hot path for gfx950 (MI355X, wave64).
 //
-// Structure ("triangle-stationary wave"): one wave64 owns an 8x8 pixel tile for all requested
-// passes.  Pixel work (ray generation, RNG, shading, accumulation) runs one pixel per lane.  The
+// Structure ("triangle-stationary wave"): one wave64 owns 64 pixels of an image row for a few
+// passes (see pt_trace_items).  Pixel work (ray generation, RNG, shading, accumulation) runs one pixel per lane.  The
 // >99 % hot loop -- brute-force ray/triangle tests against the mesh (rt.comp:213-218) -- runs the
 // other way round: every lane keeps SLOTS mesh triangles in VGPRs for the whole kernel (loaded once,
 // coalesced, from a slot-major SoA image), and the rays that passed the root-AABB gate are taken one
@@ -45,9 +45,12 @@ struct FrameParams {
     float cam[3];
     float iv[9];              // inverseView columns 0,1,2 (xyz each); column 3 and row w are never read (rt.comp:333)
     int max_bounces, debug_normal;
-    int first_pass, n_passes;
+    int first_pass, n_passes; // passes of this batch: first_pass .. first_pass + n_passes - 1
+    int chunk;                // passes per work item
+    int traced_width, rows, x_blocks;   // (W/8)*8, (H/8)*8 (glDispatchCompute(W/8, H/8, 1)), ceil(traced_width/64)
     int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
     float *accum;             // RGBA32F, row 0 = bottom
+    float4 *radiance;         // [n_passes][H][W] 1-spp radiance of this batch
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
@@ -210,88 +213,102 @@ __device__ __forceinline__ uint32_t primary_ray(const FrameParams &fp, int x, in
     return state;
 }
 
-// RayTrace (rt.comp:256-323) for the pixel of this lane; all 64 lanes must call it together.
-template <int SLOTS>
-__device__ __forceinline__ v3 ray_trace(const SceneView &sc, const FrameParams &fp, TriRegs<SLOTS> &T, int lane, v3 o, v3 d,
-                                        uint32_t &state, unsigned &n_seg, unsigned &n_mesh_seg, unsigned &n_hits)
+// One bounce of RayTrace's loop body for a path that hit (rt.comp:276-311).
+struct PathState { v3 o, d, ray_color, incoming, emitted; uint32_t rng; int bounces; };
+
+__device__ __forceinline__ void shade_hit(const SceneView &sc, const Hit &h, PathState &ps)
 {
-    v3 ray_color = V(1, 1, 1), incoming = V(0, 0, 0), emitted = V(0, 0, 0);
-    const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;       // rt.comp:23
-    int bounces = 0;
-    bool alive = true;
-    v3 result = V(0, 0, 0);
-    bool returned_normal = false;
-    for (int i = 0; i < max_bounces; i++) {
-        if (!__any(alive)) break;
-        Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, o, d, n_seg, n_mesh_seg);
-        n_hits += __popcll(__ballot(alive && h.id >= 0 && h.t < kInfinity));
-        if (!alive) {
-            // finished path: this lane only helps the wave-cooperative mesh test above
-        } else if (h.id >= 0 && h.t < kInfinity && fp.debug_normal) {
-            result = h.normal; returned_normal = true; alive = false;                                        // rt.comp:274
-        } else if (h.id >= 0 && h.t < kInfinity) {
-            bounces++;
-            const PtMaterial *m = &sc.mats[h.mat];
-            const float m_ior = m->ior, m_smooth = m->smoothness, m_spec_smooth = m->specularSmoothness;
-            o = o + d * h.t;                                            // hitPoint (rt.comp:175 / :144)
-            const float ior = h.front ? (1.0f / m_ior) : m_ior;
-            const bool is_spec = m->specularChance > random_value(state);
-            const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, d, 1.0f - m->refractionAmount);
-            const bool is_refr = fres < random_value(state);
-            const v3 hemi = random_in_hemisphere(h.normal, state);
-            const v3 a = mix3(hemi, reflect3(d, h.normal), is_spec ? m_spec_smooth : m_smooth);
-            const v3 b = mix3(-hemi, refract3(d, h.normal, ior), m_smooth);
-            d = normalize(select3(is_refr, b, a));
-            o = o + d * 0.0002f;                                        // rt.comp:305
-            const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
-            const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
-            emitted = emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
-            ray_color = ray_color * select3(is_refr, base, select3(is_spec, spec, base));
-            incoming = incoming + emitted * ray_color;
-        } else {
-            bounces++;
-            emitted = emitted + V(0.5f, 0.5f, 0.5f);                    // skyColor * skyIntensity (rt.comp:315)
-            incoming = incoming + emitted * ray_color;                 // rayColor *= vec3(1) is exact
-            alive = false;                                              // break (rt.comp:318)
-        }
-    }
-    if (returned_normal) return result;
-    const float nb = (float)bounces;
-    return V(incoming.x / nb, incoming.y / nb, incoming.z / nb);      // rt.comp:322
+    ps.bounces++;
+    const PtMaterial *m = &sc.mats[h.mat];
+    const float m_ior = m->ior, m_smooth = m->smoothness, m_spec_smooth = m->specularSmoothness;
+    v3 o = ps.o + ps.d * h.t;                                           // hitPoint (rt.comp:175 / :144)
+    const float ior = h.front ? (1.0f / m_ior) : m_ior;
+    const bool is_spec = m->specularChance > random_value(ps.rng);
+    const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);
+    const bool is_refr = fres < random_value(ps.rng);
+    const v3 hemi = random_in_hemisphere(h.normal, ps.rng);
+    const v3 a = mix3(hemi, reflect3(ps.d, h.normal), is_spec ? m_spec_smooth : m_smooth);
+    const v3 b = mix3(-hemi, refract3(ps.d, h.normal, ior), m_smooth);
+    ps.d = normalize(select3(is_refr, b, a));
+    ps.o = o + ps.d * 0.0002f;                                          // rt.comp:305
+    const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
+    const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
+    ps.emitted = ps.emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
+    ps.ray_color = ps.ray_color * select3(is_refr, base, select3(is_spec, spec, base));
+    ps.incoming = ps.incoming + ps.emitted * ps.ray_color;
 }
 
 // ------------------------------------------------------------------------------------------------
-// The hot kernel: grid = (W/8)*(H/8) single-wave workgroups, like glDispatchCompute(W/8, H/8, 1).
+// The hot kernel.  Work item (= one single-wave workgroup) = 64 consecutive pixels of one image row x
+// `fp.chunk` consecutive passes.  Each lane owns one pixel and walks through its passes on its own
+// ("persistent lane": when a path ends the lane starts the primary ray of its next pass at once), so
+// lanes stay busy although path lengths differ; a sample is a pure function of (pixel, pass)
+// (rt.comp:326-327), so this changes no result.  The 1-spp radiance of every (pass, pixel) goes to
+// fp.radiance; pt_accumulate applies the reference's running mean in pass order (rt.comp:337-339).
+// Items are ordered pass-chunk-major so that every sweep over the image ends in cheap sky rows.
 template <int SLOTS>
-__global__ void __launch_bounds__(kWave, 3) pt_trace_tiles(SceneView sc, FrameParams fp)
+__global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
 {
     const int lane = threadIdx.x;
-    const int tiles_x = fp.width >> 3;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const int item = blockIdx.x;
+    const int xb = item % fp.x_blocks;
+    const int y = (item / fp.x_blocks) % fp.rows;
+    const int chunk = item / (fp.x_blocks * fp.rows);
+    const int x = xb * kWave + lane;
+    const bool valid = x < fp.traced_width;
+    const int k0 = chunk * fp.chunk;                                   // first pass of this item, relative to fp.first_pass
+    const int k_end = min(fp.n_passes, k0 + fp.chunk);
 
     TriRegs<SLOTS> T;
     if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
 
-    float4 *px = reinterpret_cast<float4 *>(fp.accum) + ((size_t)y * fp.width + x);
-    const float4 prev = *px;
-    v3 acc = V(prev.x, prev.y, prev.z);
-    unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0;
-    for (int k = 0; k < fp.n_passes; k++) {
-        const int pass = fp.first_pass + k;
-        v3 o, d;
-        uint32_t state = primary_ray(fp, x, y, pass, o, d);
-        const v3 c = ray_trace<SLOTS>(sc, fp, T, lane, o, d, state, n_seg, n_mesh_seg, n_hits);
-        if (fp.sum_mode) {
-            acc = acc + c;
-        } else {
-            const float t = 1.0f / (float)pass;                         // rt.comp:337
-            acc = mix3(acc, c, t);
+    const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
+    const size_t plane = (size_t)fp.width * fp.height;
+    float4 *rad = fp.radiance + (size_t)y * fp.width + x;
+    unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0, n_samples = 0;
+    int k = k0;
+    bool fresh = true;                                                 // lane needs the primary ray of pass k
+    PathState ps;
+    ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
+    for (;;) {
+        const bool alive = valid && k < k_end;
+        if (!__any(alive)) break;
+        if (alive && fresh) {
+            ps.rng = primary_ray(fp, x, y, fp.first_pass + k, ps.o, ps.d);
+            ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
+            fresh = false;
+        }
+        n_samples += __popcll(__ballot(alive && ps.bounces == 0));
+        Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, ps.o, ps.d, n_seg, n_mesh_seg);
+        const bool hit = h.id >= 0 && h.t < kInfinity;
+        n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
+        if (alive) {
+            bool done;
+            v3 colour;
+            if (hit && fp.debug_normal) {
+                colour = h.normal; done = true;                         // rt.comp:274
+            } else {
+                if (hit) {
+                    shade_hit(sc, h, ps);
+                    done = ps.bounces >= max_bounces;
+                } else {
+                    ps.bounces++;
+                    ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);      // skyColor * skyIntensity (rt.comp:315)
+                    ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
+                    done = true;                                        // break (rt.comp:318)
+                }
+                const float nb = (float)ps.bounces;
+                colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
+            }
+            if (done) {
+                rad[(size_t)k * plane] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                k++;
+                fresh = true;
+            }
         }
     }
-    *px = make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? prev.w + (float)fp.n_passes : 1.0f);
     if (lane == 0 && fp.counters) {
-        atomicAdd(&fp.counters[0], (unsigned long long)kWave * fp.n_passes);
+        atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
         atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
         atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
         atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
@@ -299,20 +316,45 @@ __global__ void __launch_bounds__(kWave, 3) pt_trace_tiles(SceneView sc, FramePa
     }
 }
 
+// rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
+// (sum_mode: plain sum for the multi-GPU sample split).  One thread per traced pixel.
+__global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= fp.traced_width) return;
+    const size_t plane = (size_t)fp.width * fp.height, pix = (size_t)y * fp.width + x;
+    float4 *px = reinterpret_cast<float4 *>(fp.accum) + pix;
+    const float4 prev = *px;
+    v3 acc = V(prev.x, prev.y, prev.z);
+    const float4 *rad = fp.radiance + pix;
+    for (int k = 0; k < fp.n_passes; k++) {
+        const float4 c = rad[(size_t)k * plane];
+        if (fp.sum_mode) {
+            acc = acc + V(c.x, c.y, c.z);
+        } else {
+            const float t = 1.0f / (float)(fp.first_pass + k);          // rt.comp:337
+            acc = mix3(acc, V(c.x, c.y, c.z), t);
+        }
+    }
+    *px = make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? prev.w + (float)fp.n_passes : 1.0f);
+}
+
 // Test-only probe: primary ray + CalculateRay per pixel (pt_read_primary_hits).
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave, 3) pt_primary_hits(SceneView sc, FrameParams fp)
 {
     const int lane = threadIdx.x;
-    const int tiles_x = fp.width >> 3;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const int xb = blockIdx.x % fp.x_blocks, y = blockIdx.x / fp.x_blocks;
+    const int x = xb * kWave + lane;
+    const bool valid = x < fp.traced_width;
     TriRegs<SLOTS> T;
     if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
-    v3 o, d;
-    uint32_t state = primary_ray(fp, x, y, fp.first_pass, o, d);
+    v3 o = V(0, 0, 0), d = V(0, 0, 1);
+    uint32_t state = 0;
+    if (valid) state = primary_ray(fp, x, y, fp.first_pass, o, d);
     unsigned a = 0, b = 0;
-    Hit h = calculate_ray<SLOTS>(sc, T, lane, true, o, d, a, b);
+    Hit h = calculate_ray<SLOTS>(sc, T, lane, valid, o, d, a, b);
+    if (!valid) return;
     const size_t i = (size_t)y * fp.width + x;
     if (fp.out_ids) fp.out_ids[i] = h.id;
     if (fp.out_t) fp.out_t[i] = h.t;

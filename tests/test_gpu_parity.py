@@ -229,3 +229,24 @@ def test_error_behaviour(capi, cameras, scenes):
     assert L.pt_set_max_bounces(h, 0) == capi.PT_E_INVALID
     assert L.pt_create(C.byref(C.c_void_p()), 9999) == capi.PT_E_INVALID
     L.pt_destroy(h)
+
+
+def test_workspace_batches_and_item_sizes_do_not_change_results(capi, cameras, scenes):
+    """the per-pass radiance workspace may be split into batches and passes grouped per work item in any
+    way: the image must stay bit-identical"""
+    W, H, SPP = 128, 72, 10
+    ref = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
+    ref.render(1, SPP)
+    want = ref.read_accum()
+    for chunk, limit in ((1, 0), (3, 0), (64, 0), (4, 3 * W * H * 16), (2, 1)):
+        r = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
+        r.set_tuning(chunk, limit)
+        r.render(1, SPP)
+        ms, launches = r.last_render_launches()
+        assert bits_equal(r.read_accum(), want), (chunk, limit)
+        if limit == 1:
+            assert launches == SPP
+        elif limit:
+            assert launches == 4
+        r.close()
+    ref.close()
