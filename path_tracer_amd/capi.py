@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+LIB_PATH = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "libpt_hip.so")   # PT_HIP_LIB: A/B builds of the same ABI
 
 PT_OK, PT_E_INVALID, PT_E_HIP, PT_E_STATE, PT_E_LIMIT = 0, -1, -2, -3, -4
 
@@ -75,7 +75,7 @@ def load():
     L.pt_get_counters.argtypes = [vp, C.POINTER(PtCounters)]
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
-    L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t]
+    L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32]
     L.pt_kernel_name.restype = C.c_char_p
     L.pt_version.restype = i32
     _lib = L
@@ -183,5 +183,5 @@ class Renderer:
         self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
-    def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0):
-        self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes))
+    def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0, waves_per_cu=0):
+        self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes, waves_per_cu))

@@ -47,6 +47,9 @@ struct pt_ctx {
     DevBuf radiance;                   // [batch passes][H][W] float4 workspace
     size_t workspace_limit = (size_t)4 << 30;
     int chunk_passes = 4;              // passes per work item
+    DevBuf queue;                      // work-item counter of pt_trace_items
+    int n_cus = 256;
+    int waves_per_cu = 12;             // resident single-wave workgroups per CU at 3 waves/SIMD
     std::string err;
 
     int width = 0, height = 0;
@@ -171,8 +174,11 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         const int chunks = (np + fp.chunk - 1) / fp.chunk;
         const long long items = (long long)fp.x_blocks * fp.rows * chunks;
         if (items > 0x7fffffffll) return fail(c, PT_E_LIMIT, "too many work items in one batch (%lld); lower the workspace limit", items);
+        fp.queue = (unsigned *)c->queue.p; fp.n_items = (int)items;
+        const unsigned grid = (unsigned)std::min<long long>(items, (long long)c->n_cus * c->waves_per_cu);
+        HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(unsigned), c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
-        hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3((unsigned)items), dim3(kWave), 0, c->stream, sv, fp);
+        hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3(grid), dim3(kWave), 0, c->stream, sv, fp);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
         hipLaunchKernelGGL(pt_accumulate, dim3((fp.traced_width + 255) / 256, fp.rows), dim3(256), 0, c->stream, fp);
@@ -207,7 +213,10 @@ int pt_create(pt_ctx **out, int device)
         return PT_E_HIP;
     }
     c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((e = c->queue.upload(zero, 16, c->stream)) != hipSuccess) { fail(nullptr, PT_E_HIP, "queue setup failed: %s", hipGetErrorString(e)); delete c; return PT_E_HIP; }
     if ((e = c->counters.upload(zero, sizeof zero, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "counter setup failed: %s", hipGetErrorString(e));
         delete c;
@@ -223,7 +232,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
@@ -477,9 +486,11 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
     return PT_OK;
 }
 
-int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes)
+int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu)
 {
     if (!c) return PT_E_INVALID;
+    if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
+    if (waves_per_cu) c->waves_per_cu = waves_per_cu;
     if (passes_per_item < 0 || passes_per_item > 4096) return fail(c, PT_E_INVALID, "passes_per_item outside [1,4096]");
     if (passes_per_item) c->chunk_passes = passes_per_item;
     if (workspace_limit_bytes) c->workspace_limit = workspace_limit_bytes;

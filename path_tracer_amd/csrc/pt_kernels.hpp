@@ -20,6 +20,9 @@
 
 namespace pt {
 
+#ifndef PT_SLOT_GROUP
+#define PT_SLOT_GROUP 1      // triangle slots the instruction scheduler may interleave
+#endif
 constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
@@ -51,6 +54,8 @@ struct FrameParams {
     int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
     float *accum;             // RGBA32F, row 0 = bottom
     float4 *radiance;         // [n_passes][H][W] 1-spp radiance of this batch
+    unsigned *queue;          // work-item counter, zeroed before every launch
+    int n_items;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
@@ -113,8 +118,8 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, TriRegs<SLOTS>
                 bool has = hit_triangle(V(T.p1x[s], T.p1y[s], T.p1z[s]), V(T.e1x[s], T.e1y[s], T.e1z[s]), V(T.e2x[s], T.e2y[s], T.e2z[s]),
                                         ro, rd, t, det);
                 if (has && t < lt) { lt = t; ls = s; }
-                // keep the slots sequential: interleaving 11 independent tests costs ~20 live VGPRs each
-                __builtin_amdgcn_sched_barrier(0);
+                // keep the slots (nearly) sequential: interleaving 11 independent tests costs ~20 live VGPRs each
+                if ((s + 1) % PT_SLOT_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
             }
             const float tmin = readlane_f(wave_min_to_lane63(lt), 63);
             if (tmin < kInfinity) {
@@ -239,71 +244,77 @@ __device__ __forceinline__ void shade_hit(const SceneView &sc, const Hit &h, Pat
 }
 
 // ------------------------------------------------------------------------------------------------
-// The hot kernel.  Work item (= one single-wave workgroup) = 64 consecutive pixels of one image row x
-// `fp.chunk` consecutive passes.  Each lane owns one pixel and walks through its passes on its own
-// ("persistent lane": when a path ends the lane starts the primary ray of its next pass at once), so
-// lanes stay busy although path lengths differ; a sample is a pure function of (pixel, pass)
-// (rt.comp:326-327), so this changes no result.  The 1-spp radiance of every (pass, pixel) goes to
-// fp.radiance; pt_accumulate applies the reference's running mean in pass order (rt.comp:337-339).
-// Items are ordered pass-chunk-major so that every sweep over the image ends in cheap sky rows.
+// The hot kernel.  Persistent single-wave workgroups (grid = what the chip holds at 3 waves/SIMD) pull
+// work items from an atomic queue; the mesh triangles are loaded into registers once per wave for
+// the whole launch.  Work item = 64 consecutive pixels of one image row x `fp.chunk` consecutive
+// passes.  Each lane owns one pixel and walks through its passes on its own ("persistent lane": when
+// a path ends the lane starts the primary ray of its next pass at once), so lanes stay busy although
+// path lengths differ; a sample is a pure function of (pixel, pass) (rt.comp:326-327), so this changes
+// no result.  The 1-spp radiance of every (pass, pixel) goes to fp.radiance; pt_accumulate applies the
+// reference's running mean in pass order (rt.comp:337-339).  Items are ordered pass-chunk-major so
+// that every sweep over the image ends in cheap sky rows.
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
 {
     const int lane = threadIdx.x;
-    const int item = blockIdx.x;
-    const int xb = item % fp.x_blocks;
-    const int y = (item / fp.x_blocks) % fp.rows;
-    const int chunk = item / (fp.x_blocks * fp.rows);
-    const int x = xb * kWave + lane;
-    const bool valid = x < fp.traced_width;
-    const int k0 = chunk * fp.chunk;                                   // first pass of this item, relative to fp.first_pass
-    const int k_end = min(fp.n_passes, k0 + fp.chunk);
-
     TriRegs<SLOTS> T;
     if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
 
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const size_t plane = (size_t)fp.width * fp.height;
-    float4 *rad = fp.radiance + (size_t)y * fp.width + x;
     unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0, n_samples = 0;
-    int k = k0;
-    bool fresh = true;                                                 // lane needs the primary ray of pass k
-    PathState ps;
-    ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
     for (;;) {
-        const bool alive = valid && k < k_end;
-        if (!__any(alive)) break;
-        if (alive && fresh) {
-            ps.rng = primary_ray(fp, x, y, fp.first_pass + k, ps.o, ps.d);
-            ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
-            fresh = false;
-        }
-        n_samples += __popcll(__ballot(alive && ps.bounces == 0));
-        Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, ps.o, ps.d, n_seg, n_mesh_seg);
-        const bool hit = h.id >= 0 && h.t < kInfinity;
-        n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
-        if (alive) {
-            bool done;
-            v3 colour;
-            if (hit && fp.debug_normal) {
-                colour = h.normal; done = true;                         // rt.comp:274
-            } else {
-                if (hit) {
-                    shade_hit(sc, h, ps);
-                    done = ps.bounces >= max_bounces;
-                } else {
-                    ps.bounces++;
-                    ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);      // skyColor * skyIntensity (rt.comp:315)
-                    ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
-                    done = true;                                        // break (rt.comp:318)
-                }
-                const float nb = (float)ps.bounces;
-                colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
+        // every wave leaves through this test once the queue is drained
+        unsigned fetched = 0;
+        if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
+        const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
+        if (item >= fp.n_items) break;
+        const int xb = item % fp.x_blocks;
+        const int y = (item / fp.x_blocks) % fp.rows;
+        const int chunk = item / (fp.x_blocks * fp.rows);
+        const int x = xb * kWave + lane;
+        const bool valid = x < fp.traced_width;
+        const int k_end = min(fp.n_passes, (chunk + 1) * fp.chunk);
+        float4 *rad = fp.radiance + (size_t)y * fp.width + x;
+        int k = chunk * fp.chunk;                                      // pass index relative to fp.first_pass
+        bool fresh = true;                                             // lane needs the primary ray of pass k
+        PathState ps;
+        ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
+        for (;;) {
+            const bool alive = valid && k < k_end;
+            if (!__any(alive)) break;
+            if (alive && fresh) {
+                ps.rng = primary_ray(fp, x, y, fp.first_pass + k, ps.o, ps.d);
+                ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
+                fresh = false;
             }
-            if (done) {
-                rad[(size_t)k * plane] = make_float4(colour.x, colour.y, colour.z, 1.0f);
-                k++;
-                fresh = true;
+            n_samples += __popcll(__ballot(alive && ps.bounces == 0));
+            Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, ps.o, ps.d, n_seg, n_mesh_seg);
+            const bool hit = h.id >= 0 && h.t < kInfinity;
+            n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
+            if (alive) {
+                bool done;
+                v3 colour;
+                if (hit && fp.debug_normal) {
+                    colour = h.normal; done = true;                     // rt.comp:274
+                } else {
+                    if (hit) {
+                        shade_hit(sc, h, ps);
+                        done = ps.bounces >= max_bounces;
+                    } else {
+                        ps.bounces++;
+                        ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);  // skyColor * skyIntensity (rt.comp:315)
+                        ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
+                        done = true;                                    // break (rt.comp:318)
+                    }
+                    const float nb = (float)ps.bounces;
+                    colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
+                }
+                if (done) {
+                    rad[(size_t)k * plane] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                    k++;
+                    fresh = true;
+                }
             }
         }
     }

@@ -147,13 +147,37 @@ __device__ __forceinline__ bool hit_aabb(v3 bmin, v3 bmax, v3 o, v3 d)
     return tmax >= tmin && tmax >= 0.0f;
 }
 
+#ifndef PT_FAST_RCP
+#define PT_FAST_RCP 0
+#endif
+// Correctly rounded 1/x for the hot loop.  v_rcp_f32 (<= 1 ulp) + one fused Newton step is the IEEE
+// result for every x whose result is a normal number (checked on all 2^32 bit patterns by
+// tools/rcp_exact.hip); anything else (zero, denormal, huge, inf, NaN operands) takes the full IEEE
+// divide behind a wave-uniform branch that is practically never taken.
+__device__ __forceinline__ float exact_rcp(float x)
+{
+#if PT_FAST_RCP
+    float r0 = __builtin_amdgcn_rcpf(x);
+    float e = fmaf(-x, r0, 1.0f);
+    float r = fmaf(e, r0, r0);
+    const bool bad = !__builtin_amdgcn_class(r, 0x108);          // not +-normal
+    if (__builtin_amdgcn_ballot_w64(bad)) {
+        float slow = 1.0f / x;
+        r = bad ? slow : r;
+    }
+    return r;
+#else
+    return 1.0f / x;
+#endif
+}
+
 // rt.comp:153-173 with e1 = p2-p1, e2 = p3-p1 precomputed (one rounding each, identical to the
 // shader's own subtraction).  Returns hasHit; t and det are always written.
 __device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
 {
     v3 q = cross(d, e2);
     float det = dot(e1, q);
-    float inv = 1.0f / det;
+    float inv = exact_rcp(det);
     v3 s = o - p1;
     float u = inv * dot(s, q);
     v3 r = cross(s, e1);

@@ -1,17 +1,24 @@
 // rcp_exact -- exhaustive check (all 2^32 float32 bit patterns) of a cheap correctly-rounded
 // reciprocal candidate against IEEE 1.0f/x, as used by the hot loop's `inv = 1.0 / det`.
-// candidate: r0 = v_rcp_f32(x); e = fma(-x, r0, 1); r = fma(e, r0, r0)   (one Newton step)
+// candidate: pt::exact_rcp (pt_math.hpp): r0 = v_rcp_f32(x); e = fma(-x, r0, 1); r = fma(e, r0, r0), IEEE divide
+// when r is not a normal number.  -DFAST_ONLY=1 checks the bare Newton step instead.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
+#define PT_FAST_RCP 1
+#include "../path_tracer_amd/csrc/pt_math.hpp"
+#if FAST_ONLY
 __device__ __forceinline__ float cand(float x)
 {
     float r0 = __builtin_amdgcn_rcpf(x);
     float e = __builtin_fmaf(-x, r0, 1.0f);
     return __builtin_fmaf(e, r0, r0);
 }
+#else
+__device__ __forceinline__ float cand(float x) { return pt::exact_rcp(x); }   // the function the kernels use
+#endif
 
 // bins: by exponent field of x (0..255) -> mismatch count; plus first few examples
 __global__ void sweep(unsigned long long *bins, unsigned long long *total, uint32_t *examples)
