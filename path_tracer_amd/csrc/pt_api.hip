@@ -46,7 +46,7 @@ struct pt_ctx {
     int n_timed = 0;
     DevBuf radiance;                   // [batch passes][H][W] float4 workspace
     size_t workspace_limit = (size_t)4 << 30;
-    int chunk_passes = 4;              // passes per work item
+    int chunk_passes = 2;              // passes per work item
     DevBuf queue;                      // work-item counter of pt_trace_items
     int n_cus = 256;
     int waves_per_cu = 12;             // resident single-wave workgroups per CU at 3 waves/SIMD
@@ -291,13 +291,18 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int chunks = (n + kChunk - 1) / kChunk;
     std::vector<float4> p1(n), e1(n), e2(n), nr(n);
-    // padded slots: p1 = e1 = e2 = 0 -> det = 0, inv = inf, t = inf*0 = NaN -> `t > HIT_LIMIT` is false: never hits
+    // Padded slots of the last chunk hold copies of the LAST real triangle: a copy computes the same t as the
+    // original and sits in a later slot / higher lane, so it loses every tie and never changes a result (and,
+    // unlike a degenerate filler, it keeps the fast reciprocal on its exact path).
     std::vector<float> soa((size_t)chunks * 9 * kChunk, 0.0f);
     uint32_t maxm = 0;
     for (int i = 0; i < n; i++) {
         tri_precompute(tris[i], p1[i], e1[i], e2[i], nr[i]);
         if (tris[i].materialIndex > maxm) maxm = tris[i].materialIndex;
-        const int chunk = i / kChunk, r = i % kChunk, lane = r / kSlots, slot = r % kSlots;
+    }
+    for (int j = 0; j < chunks * kChunk; j++) {
+        const int i = std::min(j, n - 1);
+        const int chunk = j / kChunk, r = j % kChunk, lane = r / kSlots, slot = r % kSlots;
         float *base = soa.data() + (size_t)chunk * 9 * kChunk + slot * kWave + lane;
         const float comp[9] = {p1[i].x, p1[i].y, p1[i].z, e1[i].x, e1[i].y, e1[i].z, e2[i].x, e2[i].y, e2[i].z};
         for (int k = 0; k < 9; k++) base[(size_t)k * kChunk] = comp[k];

@@ -76,6 +76,21 @@ __device__ __forceinline__ void load_chunk(TriRegs<SLOTS> &T, const float *__res
     }
 }
 
+// Load through the constant address space: the scene arrays are never written while a kernel runs, and
+// with a wave-uniform index hipcc then issues an s_load (scalar cache, result in SGPRs) instead of 64
+// identical vector loads.
+__device__ __forceinline__ float4 uniform_load(const float4 *p, int i)
+{
+#if PT_SLOAD
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(4))) const f4v cf4v;
+    const f4v v = *reinterpret_cast<cf4v *>(reinterpret_cast<uintptr_t>(p + i));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return p[i];
+#endif
+}
+
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // wave64 minimum through DPP (no LDS): prefix-min inside each row of 16, then row broadcasts; the
@@ -94,6 +109,23 @@ __device__ __forceinline__ float wave_min_to_lane63(float v)
     return v;
 }
 
+// One broadcast ray against the SLOTS triangles this lane holds: local closest hit (lt, ls).
+template <int SLOTS, bool FAST>
+__device__ __forceinline__ void test_slots(const TriRegs<SLOTS> &T, v3 ro, v3 rd, float &lt, int &ls, bool &bad)
+{
+    lt = kInfinity;
+    ls = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        float t, det;
+        bool has = hit_triangle_t<FAST>(V(T.p1x[s], T.p1y[s], T.p1z[s]), V(T.e1x[s], T.e1y[s], T.e1z[s]), V(T.e2x[s], T.e2y[s], T.e2z[s]),
+                                        ro, rd, t, det, bad);
+        if (has && t < lt) { lt = t; ls = s; }
+        // keep the slots (nearly) sequential: interleaving 11 independent tests costs ~20 live VGPRs each
+        if ((s + 1) % PT_SLOT_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Closest mesh hit for every lane whose bit is set in `mask` (wave-uniform).  best_t/best_id are the
 // per-pixel-lane results (kInfinity / -1 when nothing is hit).  rt.comp:213-218.
 template <int SLOTS>
@@ -110,17 +142,15 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, TriRegs<SLOTS>
             // broadcast the ray through SGPRs
             const v3 ro = V(readlane_f(o.x, src), readlane_f(o.y, src), readlane_f(o.z, src));
             const v3 rd = V(readlane_f(d.x, src), readlane_f(d.y, src), readlane_f(d.z, src));
-            float lt = kInfinity;
-            int ls = 0;
-#pragma unroll
-            for (int s = 0; s < SLOTS; s++) {
-                float t, det;
-                bool has = hit_triangle(V(T.p1x[s], T.p1y[s], T.p1z[s]), V(T.e1x[s], T.e1y[s], T.e1z[s]), V(T.e2x[s], T.e2y[s], T.e2z[s]),
-                                        ro, rd, t, det);
-                if (has && t < lt) { lt = t; ls = s; }
-                // keep the slots (nearly) sequential: interleaving 11 independent tests costs ~20 live VGPRs each
-                if ((s + 1) % PT_SLOT_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
-            }
+            float lt;
+            int ls;
+            bool bad = false;
+#if PT_FAST_RCP
+            test_slots<SLOTS, true>(T, ro, rd, lt, ls, bad);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) test_slots<SLOTS, false>(T, ro, rd, lt, ls, bad);
+#else
+            test_slots<SLOTS, false>(T, ro, rd, lt, ls, bad);
+#endif
             const float tmin = readlane_f(wave_min_to_lane63(lt), 63);
             if (tmin < kInfinity) {
                 const unsigned long long winners = __ballot(lt == tmin);
@@ -156,7 +186,7 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, TriRegs<SLOTS>
     float win_det = 0.0f;
     int win_tri = -1;   // scene-triangle index of the current winner, if it is one
     for (int i = 0; i < sc.n_tris; i++) {
-        float4 p1 = sc.tri_p1[i], e1 = sc.tri_e1[i], e2 = sc.tri_e2[i];
+        const float4 p1 = uniform_load(sc.tri_p1, i), e1 = uniform_load(sc.tri_e1, i), e2 = uniform_load(sc.tri_e2, i);
         float t, det;
         bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
         if (has && t < h.t) { h.t = t; h.id = sc.n_mesh + i; win_tri = i; win_det = det; }
@@ -164,7 +194,7 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, TriRegs<SLOTS>
     bool sph_front = false;
     int win_sph = -1;
     for (int i = 0; i < sc.n_sph; i++) {
-        float4 s = sc.sph[i];
+        const float4 s = uniform_load(sc.sph, i);
         float t; bool front;
         bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
         if (has && t < h.t) { h.t = t; h.id = sc.n_mesh + sc.n_tris + i; win_sph = i; sph_front = front; }

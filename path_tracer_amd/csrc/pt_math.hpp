@@ -148,36 +148,42 @@ __device__ __forceinline__ bool hit_aabb(v3 bmin, v3 bmax, v3 o, v3 d)
 }
 
 #ifndef PT_FAST_RCP
-#define PT_FAST_RCP 0
+#define PT_FAST_RCP 1
 #endif
-// Correctly rounded 1/x for the hot loop.  v_rcp_f32 (<= 1 ulp) + one fused Newton step is the IEEE
-// result for every x whose result is a normal number (checked on all 2^32 bit patterns by
-// tools/rcp_exact.hip); anything else (zero, denormal, huge, inf, NaN operands) takes the full IEEE
-// divide behind a wave-uniform branch that is practically never taken.
-__device__ __forceinline__ float exact_rcp(float x)
+#ifndef PT_MINMAX
+#define PT_MINMAX 1
+#endif
+#ifndef PT_SLOAD
+#define PT_SLOAD 1
+#endif
+// Correctly rounded 1/x for the hot loop.  v_rcp_f32 (<= 1 ulp) + one fused Newton step equals the
+// IEEE quotient whenever the result is a normal number -- checked on all 2^32 bit patterns by
+// tools/rcp_exact.hip.  `bad` is raised otherwise (zero, denormal, huge, inf or NaN operand); the caller
+// then repeats the work with the full IEEE divide (a wave-uniform branch that is practically never taken).
+__device__ __forceinline__ float fast_rcp_checked(float x, bool &bad)
 {
-#if PT_FAST_RCP
     float r0 = __builtin_amdgcn_rcpf(x);
     float e = fmaf(-x, r0, 1.0f);
     float r = fmaf(e, r0, r0);
-    const bool bad = !__builtin_amdgcn_class(r, 0x108);          // not +-normal
-    if (__builtin_amdgcn_ballot_w64(bad)) {
-        float slow = 1.0f / x;
-        r = bad ? slow : r;
-    }
+    bad = bad || !__builtin_amdgcn_classf(r, 0x108);             // not +-normal
     return r;
-#else
-    return 1.0f / x;
-#endif
+}
+__device__ __forceinline__ float exact_rcp(float x)              // reference form for tools/rcp_exact.hip
+{
+    bool bad = false;
+    float r = fast_rcp_checked(x, bad);
+    return bad ? 1.0f / x : r;
 }
 
 // rt.comp:153-173 with e1 = p2-p1, e2 = p3-p1 precomputed (one rounding each, identical to the
 // shader's own subtraction).  Returns hasHit; t and det are always written.
-__device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
+// FAST: reciprocal through fast_rcp_checked (sets `bad` when the caller must redo the test with FAST = false).
+template <bool FAST>
+__device__ __forceinline__ bool hit_triangle_t(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out, bool &bad)
 {
     v3 q = cross(d, e2);
     float det = dot(e1, q);
-    float inv = exact_rcp(det);
+    float inv = FAST ? fast_rcp_checked(det, bad) : 1.0f / det;
     v3 s = o - p1;
     float u = inv * dot(s, q);
     v3 r = cross(s, e1);
@@ -185,8 +191,20 @@ __device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, fl
     float t = inv * dot(e2, r);
     t_out = t;
     det_out = det;
-    // `!(det < 0.0 && det > -0.0)` at rt.comp:173 is vacuous; NaN u/v pass the negated tests as in GLSL
+    // rt.comp:173: t > HIT_LIMIT && !(u < 0 || u > 1) && !(v < 0 || u + v > 1); the `det` clause there is
+    // vacuous.  NaN u/v pass the negated tests as in GLSL.  IEEE minNum/maxNum ignore a NaN operand, so
+    // !(min(u,v) < 0) == !(u < 0) && !(v < 0) and !(max(u,u+v) > 1) == !(u > 1) && !(u+v > 1), NaNs included.
+#if PT_MINMAX
+    const float lo = __builtin_fminf(u, v), hi = __builtin_fmaxf(u, u + v);
+    return t > kHitLimit && !(lo < 0.0f) && !(hi > 1.0f);
+#else
     return t > kHitLimit && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
+#endif
+}
+__device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
+{
+    bool bad = false;
+    return hit_triangle_t<false>(p1, e1, e2, o, d, t_out, det_out, bad);
 }
 
 // rt.comp:126-146; pow(length(v),2) folds to dot(v,v) and pow(r,2) to r*r in the reference's compiler

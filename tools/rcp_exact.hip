@@ -7,7 +7,6 @@
 #include <cstdio>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-#define PT_FAST_RCP 1
 #include "../path_tracer_amd/csrc/pt_math.hpp"
 #if FAST_ONLY
 __device__ __forceinline__ float cand(float x)
