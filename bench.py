@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--passes-per-item", type=int, default=0, help="tuning: passes per work item (0 = library default)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="tuning: persistent waves per CU (0 = library default)")
+    ap.add_argument("--variant", type=int, default=0, help="tuning: kernel variant (0 = library default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,8 +90,8 @@ def main():
     r.upload_scene(sc)
     r.SetUniformCamera(cam)
     r.SetUniform1i("maxBounces", BOUNCES)
-    if a.passes_per_item or a.waves_per_cu:
-        r.set_tuning(a.passes_per_item, 0, a.waves_per_cu)
+    if a.passes_per_item or a.waves_per_cu or a.variant:
+        r.set_tuning(a.passes_per_item, 0, a.waves_per_cu, a.variant)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")      # device memory owned by torch: the reduce reads it
     r.set_accum_buffer(accum.data_ptr(), accum.numel() * 4)
     r.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -118,8 +118,10 @@ int pt_reset_counters(pt_ctx *ctx);
 int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
 /* Tuning knobs (0 = keep): passes per work item (default 2), the byte limit of the per-pass radiance
  * workspace [passes][H][W] float4 that bounds how many passes one launch covers (default 4 GiB), and the
- * number of persistent single-wave workgroups launched per CU (default 12 = 3 waves/SIMD). */
-int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu);
+ * number of persistent single-wave workgroups launched per CU (default 12 = 3 waves/SIMD), and the kernel
+ * variant: 1 = mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = resident in a workgroup-shared LDS
+ * image at 4 / 5 / 6 waves per SIMD (meshes of at most 704 triangles; larger meshes always use 1). */
+int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
 /* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
 const char *pt_kernel_name(void);
 int pt_version(void);

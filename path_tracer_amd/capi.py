@@ -75,7 +75,7 @@ def load():
     L.pt_get_counters.argtypes = [vp, C.POINTER(PtCounters)]
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
-    L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32]
+    L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32, i32]
     L.pt_kernel_name.restype = C.c_char_p
     L.pt_version.restype = i32
     _lib = L
@@ -183,5 +183,5 @@ class Renderer:
         self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
-    def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0, waves_per_cu=0):
-        self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes, waves_per_cu))
+    def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0, waves_per_cu=0, variant=0):
+        self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes, waves_per_cu, variant))

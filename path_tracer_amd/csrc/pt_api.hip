@@ -14,6 +14,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef PT_DEFAULT_LDS_VARIANT
+#define PT_DEFAULT_LDS_VARIANT 4
+#endif
+
 using namespace pt;
 
 namespace {
@@ -50,6 +54,7 @@ struct pt_ctx {
     DevBuf queue;                      // work-item counter of pt_trace_items
     int n_cus = 256;
     int waves_per_cu = 12;             // resident single-wave workgroups per CU at 3 waves/SIMD
+    int variant = 0;                   // 0 auto, 1 VGPR-resident triangles, 2/3/4 LDS-resident at 4/5/6 waves per SIMD
     std::string err;
 
     int width = 0, height = 0;
@@ -175,10 +180,23 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         const long long items = (long long)fp.x_blocks * fp.rows * chunks;
         if (items > 0x7fffffffll) return fail(c, PT_E_LIMIT, "too many work items in one batch (%lld); lower the workspace limit", items);
         fp.queue = (unsigned *)c->queue.p; fp.n_items = (int)items;
-        const unsigned grid = (unsigned)std::min<long long>(items, (long long)c->n_cus * c->waves_per_cu);
+        int variant = c->variant ? c->variant : (c->n_chunks == 1 ? PT_DEFAULT_LDS_VARIANT : 1);
+        if (c->n_chunks != 1) variant = 1;      // the LDS image holds exactly one chunk
         HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(unsigned), c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
-        hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3(grid), dim3(kWave), 0, c->stream, sv, fp);
+        if (variant == 1) {
+            const unsigned grid = (unsigned)std::min<long long>(items, (long long)c->n_cus * c->waves_per_cu);
+            hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3(grid), dim3(kWave), 0, c->stream, sv, fp);
+        } else if (variant == 2) {
+            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 4);
+            hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 4>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+        } else if (variant == 3) {
+            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 5);
+            hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+        } else {
+            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
+            hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
         hipLaunchKernelGGL(pt_accumulate, dim3((fp.traced_width + 255) / 256, fp.rows), dim3(256), 0, c->stream, fp);
@@ -193,7 +211,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
 extern "C" {
 
 int pt_version(void) { return 1; }
-const char *pt_kernel_name(void) { return "pt_trace_items"; }
+const char *pt_kernel_name(void) { return "pt_trace_items_lds"; }
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -491,9 +509,11 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
     return PT_OK;
 }
 
-int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu)
+int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;
+    if (variant < 0 || variant > 4) return fail(c, PT_E_INVALID, "variant outside [0,4]");
+    if (variant) c->variant = variant;
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
     if (waves_per_cu) c->waves_per_cu = waves_per_cu;
     if (passes_per_item < 0 || passes_per_item > 4096) return fail(c, PT_E_INVALID, "passes_per_item outside [1,4096]");

@@ -23,6 +23,9 @@ namespace pt {
 #ifndef PT_SLOT_GROUP
 #define PT_SLOT_GROUP 1      // triangle slots the instruction scheduler may interleave
 #endif
+#ifndef PT_SCHED_MASK
+#define PT_SCHED_MASK 0      // what may cross a slot boundary (0: nothing; 0x100: DS reads, so LDS prefetch can run ahead)
+#endif
 constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
@@ -109,32 +112,65 @@ __device__ __forceinline__ float wave_min_to_lane63(float v)
     return v;
 }
 
+// Where a lane's SLOTS mesh triangles live while rays are tested against them.
+//  RegStore: in VGPRs (any mesh size; a mesh of more than one chunk is re-loaded chunk by chunk per ray batch).
+//  LdsStore: in a workgroup-shared LDS image of chunk 0 (meshes of one chunk), read back slot by slot with two
+//            ds_read_b128 + one ds_read_b32 per triangle.  Frees ~100 VGPRs -> more waves per SIMD, which is what
+//            the loop needs: one wave issues a VALU op only every ~5 cycles (tools/slot_bench.hip).
+template <int SLOTS>
+struct RegStore {
+    TriRegs<SLOTS> T;
+    const float *soa; int lane; bool resident;
+    __device__ __forceinline__ void init(const SceneView &sc, int lane_)
+    {
+        soa = sc.mesh_soa; lane = lane_; resident = sc.n_chunks == 1;
+        if (resident) load_chunk<SLOTS>(T, soa, 0, lane);
+    }
+    __device__ __forceinline__ void begin_chunk(int chunk) { if (!resident) load_chunk<SLOTS>(T, soa, chunk, lane); }
+    __device__ __forceinline__ void get(int s, v3 &p1, v3 &e1, v3 &e2) const
+    {
+        p1 = V(T.p1x[s], T.p1y[s], T.p1z[s]); e1 = V(T.e1x[s], T.e1y[s], T.e1z[s]); e2 = V(T.e2x[s], T.e2y[s], T.e2z[s]);
+    }
+};
+
+template <int SLOTS>
+struct LdsStore {
+    const float4 *A, *B; const float *C;      // LDS images, already offset by this lane: [slot][64]
+    __device__ __forceinline__ void begin_chunk(int) {}
+    __device__ __forceinline__ void get(int s, v3 &p1, v3 &e1, v3 &e2) const
+    {
+        const float4 a = A[s * kWave], b = B[s * kWave];
+        const float c = C[s * kWave];
+        p1 = V(a.x, a.y, a.z); e1 = V(a.w, b.x, b.y); e2 = V(b.z, b.w, c);
+    }
+};
+
 // One broadcast ray against the SLOTS triangles this lane holds: local closest hit (lt, ls).
-template <int SLOTS, bool FAST>
-__device__ __forceinline__ void test_slots(const TriRegs<SLOTS> &T, v3 ro, v3 rd, float &lt, int &ls, bool &bad)
+template <int SLOTS, bool FAST, class Store>
+__device__ __forceinline__ void test_slots(const Store &st, v3 ro, v3 rd, float &lt, int &ls, bool &bad)
 {
     lt = kInfinity;
     ls = 0;
 #pragma unroll
     for (int s = 0; s < SLOTS; s++) {
+        v3 p1, e1, e2;
+        st.get(s, p1, e1, e2);
         float t, det;
-        bool has = hit_triangle_t<FAST>(V(T.p1x[s], T.p1y[s], T.p1z[s]), V(T.e1x[s], T.e1y[s], T.e1z[s]), V(T.e2x[s], T.e2y[s], T.e2z[s]),
-                                        ro, rd, t, det, bad);
+        bool has = hit_triangle_t<FAST>(p1, e1, e2, ro, rd, t, det, bad);
         if (has && t < lt) { lt = t; ls = s; }
         // keep the slots (nearly) sequential: interleaving 11 independent tests costs ~20 live VGPRs each
-        if ((s + 1) % PT_SLOT_GROUP == 0) __builtin_amdgcn_sched_barrier(0);
+        if ((s + 1) % PT_SLOT_GROUP == 0) __builtin_amdgcn_sched_barrier(PT_SCHED_MASK);
     }
 }
 
 // Closest mesh hit for every lane whose bit is set in `mask` (wave-uniform).  best_t/best_id are the
 // per-pixel-lane results (kInfinity / -1 when nothing is hit).  rt.comp:213-218.
-template <int SLOTS>
-__device__ __forceinline__ void mesh_closest(const SceneView &sc, TriRegs<SLOTS> &T, int lane, unsigned long long mask,
+template <int SLOTS, class Store>
+__device__ __forceinline__ void mesh_closest(const SceneView &sc, Store &st, int lane, unsigned long long mask,
                                              v3 o, v3 d, float &best_t, int &best_id)
 {
-    const bool resident = sc.n_chunks == 1;      // single chunk: registers were filled once at kernel start
     for (int chunk = 0; chunk < sc.n_chunks; chunk++) {
-        if (!resident) load_chunk<SLOTS>(T, sc.mesh_soa, chunk, lane);
+        st.begin_chunk(chunk);
         unsigned long long m = mask;
         while (m) {
             const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
@@ -146,10 +182,10 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, TriRegs<SLOTS>
             int ls;
             bool bad = false;
 #if PT_FAST_RCP
-            test_slots<SLOTS, true>(T, ro, rd, lt, ls, bad);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) test_slots<SLOTS, false>(T, ro, rd, lt, ls, bad);
+            test_slots<SLOTS, true>(st, ro, rd, lt, ls, bad);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) test_slots<SLOTS, false>(st, ro, rd, lt, ls, bad);
 #else
-            test_slots<SLOTS, false>(T, ro, rd, lt, ls, bad);
+            test_slots<SLOTS, false>(st, ro, rd, lt, ls, bad);
 #endif
             const float tmin = readlane_f(wave_min_to_lane63(lt), 63);
             if (tmin < kInfinity) {
@@ -168,8 +204,8 @@ struct Hit { int id; float t; bool front; v3 normal; uint32_t mat; };
 
 // CalculateRay (rt.comp:204-232) for the pixel of this lane; `alive` lanes take part, the mesh part is
 // wave-cooperative.  Canonical ids: mesh i | n_mesh + i | n_mesh + n_tris + i | -1.
-template <int SLOTS>
-__device__ __forceinline__ Hit calculate_ray(const SceneView &sc, TriRegs<SLOTS> &T, int lane, bool alive, v3 o, v3 d,
+template <int SLOTS, class Store>
+__device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int lane, bool alive, v3 o, v3 d,
                                              unsigned &n_seg, unsigned &n_mesh_seg)
 {
     Hit h;
@@ -180,7 +216,7 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, TriRegs<SLOTS>
     const unsigned long long gate_mask = __ballot(gate);
     n_seg += __popcll(__ballot(alive));
     n_mesh_seg += __popcll(gate_mask);
-    if (gate_mask) mesh_closest<SLOTS>(sc, T, lane, gate_mask, o, d, h.t, h.id);
+    if (gate_mask) mesh_closest<SLOTS>(sc, st, lane, gate_mask, o, d, h.t, h.id);
     if (!alive) return h;
 
     float win_det = 0.0f;
@@ -283,13 +319,9 @@ __device__ __forceinline__ void shade_hit(const SceneView &sc, const Hit &h, Pat
 // no result.  The 1-spp radiance of every (pass, pixel) goes to fp.radiance; pt_accumulate applies the
 // reference's running mean in pass order (rt.comp:337-339).  Items are ordered pass-chunk-major so
 // that every sweep over the image ends in cheap sky rows.
-template <int SLOTS>
-__global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
+template <int SLOTS, class Store>
+__device__ __forceinline__ void trace_items_body(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
 {
-    const int lane = threadIdx.x;
-    TriRegs<SLOTS> T;
-    if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
-
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const size_t plane = (size_t)fp.width * fp.height;
     unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0, n_samples = 0;
@@ -319,7 +351,7 @@ __global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FramePa
                 fresh = false;
             }
             n_samples += __popcll(__ballot(alive && ps.bounces == 0));
-            Hit h = calculate_ray<SLOTS>(sc, T, lane, alive, ps.o, ps.d, n_seg, n_mesh_seg);
+            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.o, ps.d, n_seg, n_mesh_seg);
             const bool hit = h.id >= 0 && h.t < kInfinity;
             n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
             if (alive) {
@@ -357,6 +389,38 @@ __global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FramePa
     }
 }
 
+// VGPR-resident triangles: persistent single-wave workgroups, 3 waves/SIMD (any mesh size).
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
+{
+    RegStore<SLOTS> st;
+    st.init(sc, threadIdx.x);
+    trace_items_body<SLOTS>(sc, fp, st, threadIdx.x);
+}
+
+// LDS-resident triangles (meshes of one chunk): persistent 4-wave workgroups that share one 25 KB LDS image
+// of the chunk; after the staging barrier the waves never synchronise again (each pulls its own items).
+constexpr int kLdsBlock = 256;
+template <int SLOTS, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(kLdsBlock, WAVES_PER_SIMD) pt_trace_items_lds(SceneView sc, FrameParams fp)
+{
+    __shared__ float4 ldsA[SLOTS * kWave];
+    __shared__ float4 ldsB[SLOTS * kWave];
+    __shared__ float ldsC[SLOTS * kWave];
+    for (int i = threadIdx.x; i < SLOTS * kWave; i += kLdsBlock) {     // i = slot*64 + lane, the order of the global SoA image
+        const float *g = sc.mesh_soa + i;
+        const int n = SLOTS * kWave;
+        ldsA[i] = make_float4(g[0], g[n], g[2 * n], g[3 * n]);
+        ldsB[i] = make_float4(g[4 * n], g[5 * n], g[6 * n], g[7 * n]);
+        ldsC[i] = g[8 * n];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    LdsStore<SLOTS> st;
+    st.A = ldsA + lane; st.B = ldsB + lane; st.C = ldsC + lane;
+    trace_items_body<SLOTS>(sc, fp, st, lane);
+}
+
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
 // (sum_mode: plain sum for the multi-GPU sample split).  One thread per traced pixel.
 __global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
@@ -388,13 +452,13 @@ __global__ void __launch_bounds__(kWave, 3) pt_primary_hits(SceneView sc, FrameP
     const int xb = blockIdx.x % fp.x_blocks, y = blockIdx.x / fp.x_blocks;
     const int x = xb * kWave + lane;
     const bool valid = x < fp.traced_width;
-    TriRegs<SLOTS> T;
-    if (sc.n_chunks == 1) load_chunk<SLOTS>(T, sc.mesh_soa, 0, lane);
+    RegStore<SLOTS> st;
+    st.init(sc, lane);
     v3 o = V(0, 0, 0), d = V(0, 0, 1);
     uint32_t state = 0;
     if (valid) state = primary_ray(fp, x, y, fp.first_pass, o, d);
     unsigned a = 0, b = 0;
-    Hit h = calculate_ray<SLOTS>(sc, T, lane, valid, o, d, a, b);
+    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, o, d, a, b);
     if (!valid) return;
     const size_t i = (size_t)y * fp.width + x;
     if (fp.out_ids) fp.out_ids[i] = h.id;

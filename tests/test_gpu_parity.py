@@ -231,6 +231,21 @@ def test_error_behaviour(capi, cameras, scenes):
     L.pt_destroy(h)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+def test_kernel_variants_are_bit_identical(capi, variant, meta, cameras, scenes):
+    """VGPR-resident and LDS-resident triangle stores must give the reference image (config 1 CRC) alike"""
+    r = make(capi, scenes["default"], cameras["bench"], 640, 360, 4)
+    r.set_tuning(0, 0, 0, variant)
+    r.render(1, 16)
+    assert crc(r.read_accum()[:, :, :3]) == meta["radiance_default_b4_640x360"]["crc_mean16"]
+    r.close()
+    r = make(capi, scenes["mixed"], cameras["mixed"], 640, 360, 16)
+    r.set_tuning(0, 0, 0, variant)
+    r.render(1, 4)
+    assert crc(r.read_accum()[:, :, :3]) == meta["radiance_mixed_b16_640x360"]["crc_mean4"]
+    r.close()
+
+
 def test_workspace_batches_and_item_sizes_do_not_change_results(capi, cameras, scenes):
     """the per-pass radiance workspace may be split into batches and passes grouped per work item in any
     way: the image must stay bit-identical"""
