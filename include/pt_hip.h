@@ -51,6 +51,7 @@ typedef struct PtCounters {
     uint64_t mesh_segments;  /* segments that passed the root-AABB gate (rt.comp:213)           */
     uint64_t mesh_tri_tests; /* ray-triangle tests against mesh triangles, padded slots included */
     uint64_t hits;           /* segments that hit something and were shaded (rt.comp:273-311)   */
+    uint64_t wave_iterations;/* bounce-loop iterations executed by waves (64 lanes each)        */
 } PtCounters;
 
 /* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */

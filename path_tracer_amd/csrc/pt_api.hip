@@ -480,7 +480,7 @@ int pt_get_counters(pt_ctx *c, PtCounters *out)
     unsigned long long v[8];
     HIPCHK(c, hipMemcpyAsync(v, c->counters.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3]; out->hits = v[4];
+    out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3]; out->hits = v[4]; out->wave_iterations = v[5];
     return PT_OK;
 }
 

@@ -59,7 +59,7 @@ struct FrameParams {
     float4 *radiance;         // [n_passes][H][W] 1-spp radiance of this batch
     unsigned *queue;          // work-item counter, zeroed before every launch
     int n_items;
-    unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits
+    unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
 };
@@ -324,7 +324,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 {
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const size_t plane = (size_t)fp.width * fp.height;
-    unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0, n_samples = 0;
+    unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
     for (;;) {
         // every wave leaves through this test once the queue is drained
         unsigned fetched = 0;
@@ -345,6 +345,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         for (;;) {
             const bool alive = valid && k < k_end;
             if (!__any(alive)) break;
+            n_iter++;
             if (alive && fresh) {
                 ps.rng = primary_ray(fp, x, y, fp.first_pass + k, ps.o, ps.d);
                 ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
@@ -386,6 +387,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
         atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
         atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
+        atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
     }
 }
 
