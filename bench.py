@@ -77,7 +77,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from path_tracer_amd import capi, scene as S
+    from path_tracer_amd import capi, distributed as D, scene as S
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: path_tracer_amd has no CPU path")
@@ -96,17 +96,13 @@ def main():
     r.set_accum_buffer(accum.data_ptr(), accum.numel() * 4)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    first = rank * SPP + 1
-
     def step():
-        accum.zero_()
         if world == 1:
+            accum.zero_()
             r.render(1, SPP)                                                 # reference semantics, bit-exact
         else:
-            r.render_sum(first, SPP)
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)                  # the one exchange step (RCCL over xGMI)
-            if rank == 0:
-                r.scale_accum(1.0 / (SPP * world))
+            # rank g traces passes g*SPP+1 .. (g+1)*SPP as a sum; ONE reduce onto rank 0 (RCCL over xGMI); rank 0 scales
+            D.render_split(r, accum, SPP * world)
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,123 @@
+// Main.cpp — headless counterpart of the reference's main() (src/Main.cpp:9-174): same five materials, same
+// mesh + light + ground scene, same per-frame sequence (currAccumPass++, SetUniform1i, SetUniformCamera,
+// dispatch), with the window loop replaced by "render --spp passes, write the image".
+//   pt_main --mesh bunny1.obj [--scene default|mixed] [--width 1920 --height 1080] [--spp 64] [--bounces 8]
+//           [--cam x y z yaw pitch] [--debug-normal] [--batch] [--out accum.f32] [--ppm image.ppm] [--device 0]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "Renderer.h"
+
+using namespace ptm;
+
+static void default_materials(Scene &scene)
+{
+    Material specular;
+    specular.baseColor = vec4(0.2, 0.9, 0.1, 1.0); specular.smoothness = 0.9f; specular.emissionColor = vec4(0);
+    scene.materials.push_back(specular);
+    Material diffuse;
+    diffuse.baseColor = vec4(0.9, 0.1, 0.1, 1.0); diffuse.smoothness = 0.2f; diffuse.specularSmoothness = 0.99f;
+    diffuse.specularChance = 0.1f; diffuse.emissionColor = vec4(0);
+    scene.materials.push_back(diffuse);
+    Material glass;
+    glass.baseColor = vec4(0.9, 0.1, 0.1, 1.0); glass.smoothness = 0.99f; glass.specularSmoothness = 0.99f;
+    glass.specularChance = 0.2f; glass.emissionColor = vec4(0); glass.refractionAmount = 0.8f; glass.ior = 1.05f;
+    scene.materials.push_back(glass);
+    Material ground;
+    ground.baseColor = vec4(0.9, 0.9, 0.9, 1.0); ground.emissionColor = vec4(0);
+    scene.materials.push_back(ground);
+    Material sun;
+    sun.baseColor = vec4(1.0f); sun.emissionColor = vec4(1.0f); sun.emissionStrength = 5.0f;
+    scene.materials.push_back(sun);
+}
+
+int main(int argc, char **argv)
+{
+    std::string mesh_path = "res/meshes/bunny1.obj", scene_name = "default", out_path, ppm_path;
+    int width = 1920, height = 1080, spp = 64, bounces = 8, device = 0;
+    bool debugNormal = false, batch = false, cam_given = false, print_camera = false;
+    float cam[5] = {1.5f, 0.4f, 0.0f, 0.0f, 0.0f};
+    for (int i = 1; i < argc; i++) {
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
+        if (!std::strcmp(argv[i], "--mesh")) mesh_path = next();
+        else if (!std::strcmp(argv[i], "--scene")) scene_name = next();
+        else if (!std::strcmp(argv[i], "--width")) width = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--height")) height = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--spp")) spp = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--bounces")) bounces = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next());
+        else if (!std::strcmp(argv[i], "--out")) out_path = next();
+        else if (!std::strcmp(argv[i], "--ppm")) ppm_path = next();
+        else if (!std::strcmp(argv[i], "--debug-normal")) debugNormal = true;
+        else if (!std::strcmp(argv[i], "--batch")) batch = true;
+        else if (!std::strcmp(argv[i], "--print-camera")) print_camera = true;
+        else if (!std::strcmp(argv[i], "--cam")) { for (int k = 0; k < 5; k++) cam[k] = std::strtof(next(), nullptr); cam_given = true; }
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (print_camera) {     // host-only check of Camera::UpdateView (no GPU needed): 16 hex words, column-major
+        Camera c(vec3(cam[0], cam[1], cam[2]));
+        c.yaw = cam[3]; c.pitch = cam[4];
+        c.UpdateView();
+        for (int k = 0; k < 16; k++) { unsigned u; std::memcpy(&u, c.inverseView.data() + k, 4); std::printf("%08x%c", u, k == 15 ? '\n' : ' '); }
+        return 0;
+    }
+    const bool mixed = scene_name == "mixed";
+    if (mixed && !cam_given) { cam[0] = 1.5f; cam[1] = 0.8f; cam[2] = 1.5f; cam[3] = 45.0f; cam[4] = 20.0f; }
+
+    if (Renderer::Init(width, height, device)) return 1;
+    ComputeProgram computeProgram("rt");
+    ShaderProgram computeAccumProgram;
+
+    default_materials(Renderer::scene);
+    Mesh mesh(mesh_path.c_str(), mixed ? 1 : 3);
+    if (!mesh.ok()) return 1;
+    Triangle(Renderer::scene, vec3(-1.0, 0.0, 3.0), vec3(1.0, 0.0, 3.0), vec3(0.0, 1.4, 3.0), 4);
+    Triangle(Renderer::scene, vec3(5000.0, 0.0, 5000.0), vec3(-5000.0, 0.0, 5000.0), vec3(0.0, 0.0, -5000.0), 3);
+    if (mixed) {    // the sphere grid main() carries commented out
+        for (int i = -6; i < 6; i++)
+            for (int k = -6; k < 6; k++)
+                Sphere(Renderer::scene, vec3(((float)i) / 3.0, ((float)0) + 0.101, ((float)k) / 3.0), 0.1f, 2);
+        Sphere(Renderer::scene, vec3(-0.2, 1.0, 0.0), 0.5f, 0);
+    }
+    Renderer::scene.SetupSSBOs();
+
+    Renderer::camera.position = vec3(cam[0], cam[1], cam[2]);
+    Renderer::camera.yaw = cam[3];
+    Renderer::camera.pitch = cam[4];
+    Renderer::camera.UpdateView();
+    computeProgram.SetUniform1i("debugNormal", debugNormal);
+    computeProgram.SetUniform1i("maxBounces", bounces);
+    computeProgram.SetUniformCamera(Renderer::camera);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    if (batch) {
+        if (!Renderer::Check(pt_render(Renderer::ctx, 1, spp), "pt_render")) return 1;
+    } else {
+        int currAccumPass = 0;
+        for (int frame = 0; frame < spp; frame++) {
+            currAccumPass++;
+            computeProgram.SetUniform1i("currAccumPass", currAccumPass);
+            computeProgram.SetUniformCamera(Renderer::camera);
+            computeProgram.Dispatch();
+        }
+    }
+    if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("Samples: %d | %.3f ms | %.1f Msamples/s\n", spp, dt * 1e3, (double)width * height * spp / dt * 1e-6);
+
+    if (!out_path.empty()) {
+        std::vector<float> img((size_t)width * height * 4);
+        if (!Renderer::Check(pt_read_accum(Renderer::ctx, img.data(), img.size() * sizeof(float)), "pt_read_accum")) return 1;
+        FILE *f = std::fopen(out_path.c_str(), "wb");
+        if (!f) { std::perror(out_path.c_str()); return 1; }
+        std::fwrite(img.data(), sizeof(float), img.size(), f);
+        std::fclose(f);
+    }
+    if (!ppm_path.empty() && !computeAccumProgram.Present(ppm_path.c_str())) return 1;
+    Renderer::Shutdown();
+    return 0;
+}
