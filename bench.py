@@ -92,9 +92,13 @@ def main():
     r.SetUniform1i("maxBounces", BOUNCES)
     if a.passes_per_item or a.waves_per_cu or a.variant:
         r.set_tuning(a.passes_per_item, 0, a.waves_per_cu, a.variant)
+    # one explicit stream for everything in a step (memset, trace, accumulate, RCCL reduce, scale): torch's
+    # legacy default stream has handle 0, which pt_set_stream reads as "use the context's own stream"
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")      # device memory owned by torch: the reduce reads it
     r.set_accum_buffer(accum.data_ptr(), accum.numel() * 4)
-    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    r.set_stream(stream.cuda_stream)
 
     def step():
         if world == 1:
