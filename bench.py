@@ -153,7 +153,9 @@ def main():
                          "algorithmic_flop_per_launch": flops_per_launch,
                          "note": "FP32 vector peak (FMA-counted); the path's parity contract forbids FMA contraction, so "
                                  "unfused mul/add can reach at most 50% of this peak (tools/valu_rate.hip)",
-                         "work_per_launch": {k: v / a.steps for k, v in c.items()}},
+                         "work_per_launch": {k: v / a.steps for k, v in c.items() if k != "wave_ticks_max"},
+                         # mean wave span / longest wave span of the persistent grid (1.0 = no tail)
+                         "wave_balance": c["wave_ticks_sum"] / max(1, c["waves"] * c["wave_ticks_max"])},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, cam)

@@ -52,6 +52,10 @@ typedef struct PtCounters {
     uint64_t mesh_tri_tests; /* ray-triangle tests against mesh triangles, padded slots included */
     uint64_t hits;           /* segments that hit something and were shaded (rt.comp:273-311)   */
     uint64_t wave_iterations;/* bounce-loop iterations executed by waves (64 lanes each)        */
+    uint64_t primary_mesh_segments; /* mesh_segments that were primary rays                      */
+    uint64_t waves;          /* persistent waves that ran                                       */
+    uint64_t wave_ticks_sum; /* sum over waves of (last item done - wave start), 100 MHz ticks  */
+    uint64_t wave_ticks_max; /* the longest such span: sum / (waves * max) = load balance       */
 } PtCounters;
 
 /* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */

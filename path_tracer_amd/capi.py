@@ -27,7 +27,8 @@ SYMBOLS = [
 
 
 class PtCounters(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("mesh_segments", C.c_uint64), ("mesh_tri_tests", C.c_uint64), ("hits", C.c_uint64), ("wave_iterations", C.c_uint64)]
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("mesh_segments", C.c_uint64), ("mesh_tri_tests", C.c_uint64), ("hits", C.c_uint64), ("wave_iterations", C.c_uint64),
+                ("primary_mesh_segments", C.c_uint64), ("waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64)]
 
 
 class PtError(RuntimeError):
@@ -168,7 +169,7 @@ class Renderer:
     def counters(self):
         c = PtCounters()
         self._ck(self.L.pt_get_counters(self.h, C.byref(c)))
-        return {"samples": c.samples, "segments": c.segments, "mesh_segments": c.mesh_segments, "mesh_tri_tests": c.mesh_tri_tests, "hits": c.hits, "wave_iterations": c.wave_iterations}
+        return {name: int(getattr(c, name)) for name, _ in PtCounters._fields_}
 
     def reset_counters(self):
         self._ck(self.L.pt_reset_counters(self.h))

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,6 +53,8 @@ struct pt_ctx {
     size_t workspace_limit = (size_t)4 << 30;
     int chunk_passes = 2;              // passes per work item
     DevBuf queue;                      // work-item counter of pt_trace_items
+    DevBuf tile_weights, tile_order, class_count;   // schedule of pt_trace_items: tiles sorted heaviest first
+    bool order_dirty = true;           // camera, scene, size or stream changed since the schedule was made
     int n_cus = 256;
     int waves_per_cu = 12;             // resident single-wave workgroups per CU at 3 waves/SIMD
     int variant = 0;                   // 0 auto, 1 VGPR-resident triangles, 2/3/4 LDS-resident at 4/5/6 waves per SIMD
@@ -173,13 +176,34 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     while ((int)c->ev.size() < 2 * n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev.push_back(e); }
     SceneView sv = scene_view(c);
     c->n_timed = 0;
+    const int n_tiles = (((c->width / 8) * 8 + kWave - 1) / kWave) * ((c->height / 8) * 8);
+    if (c->tile_order.bytes < (size_t)n_tiles * sizeof(unsigned)) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->tile_weights.release(); c->tile_order.release();
+        HIPCHK(c, hipMalloc(&c->tile_weights.p, (size_t)n_tiles * sizeof(unsigned))); c->tile_weights.bytes = (size_t)n_tiles * sizeof(unsigned);
+        HIPCHK(c, hipMalloc(&c->tile_order.p, (size_t)n_tiles * sizeof(unsigned))); c->tile_order.bytes = (size_t)n_tiles * sizeof(unsigned);
+        if (!c->class_count.p) { HIPCHK(c, hipMalloc(&c->class_count.p, 4 * sizeof(int))); c->class_count.bytes = 4 * sizeof(int); }
+        c->order_dirty = true;
+    }
     for (int bi = 0; bi < n_batches; bi++) {
         const int p0 = first_pass + bi * batch, np = std::min(batch, n_passes - bi * batch);
         FrameParams fp = frame_params(c, p0, np, sum_mode);
-        const int chunks = (np + fp.chunk - 1) / fp.chunk;
-        const long long items = (long long)fp.x_blocks * fp.rows * chunks;
+        // at most one item per (tile, pass): an upper bound for the grid and the 31-bit item index
+        const long long items = (long long)n_tiles * ((np + fp.chunk - 1) / fp.chunk);
         if (items > 0x7fffffffll) return fail(c, PT_E_LIMIT, "too many work items in one batch (%lld); lower the workspace limit", items);
-        fp.queue = (unsigned *)c->queue.p; fp.n_items = (int)items;
+        fp.queue = (unsigned *)c->queue.p; fp.n_tiles = n_tiles;
+        // passes per work item: mesh tiles `chunk`; tiles that only bounce off scene primitives and sky tiles take more
+        // passes per item (their items are short, and every item costs one ~11 ns device-wide atomic on the queue)
+        static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 16;
+        fp.class_ppi[0] = fp.chunk; fp.class_ppi[1] = std::max(1, std::min(np, mul1 * fp.chunk)); fp.class_ppi[2] = std::max(1, std::min(np, mul2 * fp.chunk));
+        fp.weights = (unsigned *)c->tile_weights.p; fp.order = (const unsigned *)c->tile_order.p; fp.class_count = (const int *)c->class_count.p;
+        if (c->order_dirty) {
+            hipLaunchKernelGGL(pt_tile_weights, dim3((unsigned)n_tiles), dim3(kWave), 0, c->stream, sv, fp);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(pt_sort_tiles, dim3(1), dim3(1024), 0, c->stream, fp.weights, (unsigned *)c->tile_order.p, (int *)c->class_count.p, n_tiles);
+            HIPCHK(c, hipGetLastError());
+            c->order_dirty = false;
+        }
         int variant = c->variant ? c->variant : (c->n_chunks == 1 ? PT_DEFAULT_LDS_VARIANT : 1);
         if (c->n_chunks != 1) variant = 1;      // the LDS image holds exactly one chunk
         HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(unsigned), c->stream));
@@ -233,7 +257,7 @@ int pt_create(pt_ctx **out, int device)
     c->stream = c->own_stream;
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
-    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zero[kNumCounters] = {0};
     if ((e = c->queue.upload(zero, 16, c->stream)) != hipSuccess) { fail(nullptr, PT_E_HIP, "queue setup failed: %s", hipGetErrorString(e)); delete c; return PT_E_HIP; }
     if ((e = c->counters.upload(zero, sizeof zero, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "counter setup failed: %s", hipGetErrorString(e));
@@ -250,7 +274,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
@@ -271,7 +295,7 @@ int pt_resize(pt_ctx *c, int width, int height)
         HIPCHK(c, hipMalloc((void **)&c->accum_own, bytes));
         c->accum_own_bytes = bytes;
     }
-    c->width = width; c->height = height;
+    c->width = width; c->height = height; c->order_dirty = true;
     c->accum = c->accum_own; c->accum_external = false;
     HIPCHK(c, hipMemsetAsync(c->accum, 0, bytes, c->stream));
     return PT_OK;
@@ -295,6 +319,7 @@ int pt_set_stream(pt_ctx *c, void *s)
     Bind b(c); HIPCHK(c, b.e);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->order_dirty = true;
     c->n_timed = 0;
     return PT_OK;
 }
@@ -333,7 +358,7 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     HIPCHK(c, hipStreamSynchronize(c->stream));    // host staging vectors die here
     c->n_mesh = n; c->n_chunks = chunks; c->max_mat_mesh = maxm;
     for (int k = 0; k < 3; k++) { c->bmin[k] = n ? nodes[0].boundsMin[k] : 0.0f; c->bmax[k] = n ? nodes[0].boundsMax[k] : 0.0f; }
-    c->have_mesh = true;
+    c->have_mesh = true; c->order_dirty = true;
     return PT_OK;
 }
 
@@ -362,7 +387,7 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     HIPCHK(c, c->mats.upload(mats, (size_t)n_mats * sizeof(PtMaterial), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_tris = n_tris; c->n_sph = n_sph; c->n_mats = n_mats; c->max_mat_scene = maxm;
-    c->have_scene = true;
+    c->have_scene = true; c->order_dirty = true;
     return PT_OK;
 }
 
@@ -372,7 +397,7 @@ int pt_set_camera(pt_ctx *c, const float pos[3], const float iv[16])
     for (int k = 0; k < 3; k++) c->cam[k] = pos[k];
     for (int col = 0; col < 3; col++)
         for (int r = 0; r < 3; r++) c->iv[col * 3 + r] = iv[col * 4 + r];
-    c->have_camera = true;
+    c->have_camera = true; c->order_dirty = true;
     return PT_OK;
 }
 
@@ -477,10 +502,11 @@ int pt_get_counters(pt_ctx *c, PtCounters *out)
 {
     if (!c || !out) return PT_E_INVALID;
     Bind b(c); HIPCHK(c, b.e);
-    unsigned long long v[8];
+    unsigned long long v[kNumCounters];
     HIPCHK(c, hipMemcpyAsync(v, c->counters.p, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3]; out->hits = v[4]; out->wave_iterations = v[5];
+    out->primary_mesh_segments = v[6]; out->waves = v[7]; out->wave_ticks_sum = v[8]; out->wave_ticks_max = v[9];
     return PT_OK;
 }
 
@@ -488,7 +514,7 @@ int pt_reset_counters(pt_ctx *c)
 {
     if (!c) return PT_E_INVALID;
     Bind b(c); HIPCHK(c, b.e);
-    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->counters.p, 0, kNumCounters * sizeof(unsigned long long), c->stream));
     return PT_OK;
 }
 

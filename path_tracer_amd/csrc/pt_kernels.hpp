@@ -28,6 +28,7 @@ namespace pt {
 #endif
 constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
+constexpr int kNumCounters = 16;
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
 struct SceneView {
@@ -58,8 +59,14 @@ struct FrameParams {
     float *accum;             // RGBA32F, row 0 = bottom
     float4 *radiance;         // [n_passes][H][W] 1-spp radiance of this batch
     unsigned *queue;          // work-item counter, zeroed before every launch
-    int n_items;
+    // schedule (pt_tile_weights + pt_sort_tiles): tiles = 64 px of a row, sorted heaviest first, in three classes
+    const unsigned *order;    // [n_tiles] tile index by rank
+    const int *class_count;   // [3] tiles per class: 0 = some pixel passes the mesh gate, 1 = hits only scene primitives, 2 = sky
+    int class_ppi[3];         // passes per work item for each class
+    unsigned *weights;        // per-tile sort key, written by pt_tile_weights
+    int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
+                                    // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
 };
@@ -95,6 +102,22 @@ __device__ __forceinline__ float4 uniform_load(const float4 *p, int i)
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// Copy a wave-uniform value into a VGPR and hide its uniformity from the compiler.  On gfx950 a VALU instruction with
+// an SGPR source issues in 4 SIMD cycles, the same mul/add/sub/fma with VGPR sources in 2 (tools/valu_mix.hip), so the
+// broadcast ray lives in VGPRs: 6 moves per ray instead of 12 slow operand reads per triangle slot.
+#ifndef PT_RAY_IN_VGPR
+#define PT_RAY_IN_VGPR 1
+#endif
+__device__ __forceinline__ float to_vgpr(float s)
+{
+#if PT_RAY_IN_VGPR
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+#else
+    return s;
+#endif
+}
 
 // wave64 minimum through DPP (no LDS): prefix-min inside each row of 16, then row broadcasts; the
 // result is valid in lane 63.  min is idempotent, so full row/bank masks with old = self are safe.
@@ -176,8 +199,8 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, Store &st, int
             const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
             m &= m - 1;
             // broadcast the ray through SGPRs
-            const v3 ro = V(readlane_f(o.x, src), readlane_f(o.y, src), readlane_f(o.z, src));
-            const v3 rd = V(readlane_f(d.x, src), readlane_f(d.y, src), readlane_f(d.z, src));
+            const v3 ro = V(to_vgpr(readlane_f(o.x, src)), to_vgpr(readlane_f(o.y, src)), to_vgpr(readlane_f(o.z, src)));
+            const v3 rd = V(to_vgpr(readlane_f(d.x, src)), to_vgpr(readlane_f(d.y, src)), to_vgpr(readlane_f(d.z, src)));
             float lt;
             int ls;
             bool bad = false;
@@ -205,8 +228,8 @@ struct Hit { int id; float t; bool front; v3 normal; uint32_t mat; };
 // CalculateRay (rt.comp:204-232) for the pixel of this lane; `alive` lanes take part, the mesh part is
 // wave-cooperative.  Canonical ids: mesh i | n_mesh + i | n_mesh + n_tris + i | -1.
 template <int SLOTS, class Store>
-__device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int lane, bool alive, v3 o, v3 d,
-                                             unsigned &n_seg, unsigned &n_mesh_seg)
+__device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int lane, bool alive, bool primary, v3 o, v3 d,
+                                             unsigned &n_seg, unsigned &n_mesh_seg, unsigned &n_prim_mesh_seg)
 {
     Hit h;
     h.id = -1; h.t = kInfinity; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
@@ -216,6 +239,7 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int
     const unsigned long long gate_mask = __ballot(gate);
     n_seg += __popcll(__ballot(alive));
     n_mesh_seg += __popcll(gate_mask);
+    n_prim_mesh_seg += __popcll(__ballot(gate && primary));
     if (gate_mask) mesh_closest<SLOTS>(sc, st, lane, gate_mask, o, d, h.t, h.id);
     if (!alive) return h;
 
@@ -317,28 +341,41 @@ __device__ __forceinline__ void shade_hit(const SceneView &sc, const Hit &h, Pat
 // a path ends the lane starts the primary ray of its next pass at once), so lanes stay busy although
 // path lengths differ; a sample is a pure function of (pixel, pass) (rt.comp:326-327), so this changes
 // no result.  The 1-spp radiance of every (pass, pixel) goes to fp.radiance; pt_accumulate applies the
-// reference's running mean in pass order (rt.comp:337-339).  Items are ordered pass-chunk-major so
-// that every sweep over the image ends in cheap sky rows.
+// reference's running mean in pass order (rt.comp:337-339).  Items are ordered tile-major over the tiles
+// sorted heaviest first (pt_tile_weights / pt_sort_tiles), so the launch ends in one-iteration sky tiles and the
+// persistent waves finish together.
 template <int SLOTS, class Store>
 __device__ __forceinline__ void trace_items_body(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
 {
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const size_t plane = (size_t)fp.width * fp.height;
-    unsigned n_seg = 0, n_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
+    unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
+    const unsigned long long t_start = wall_clock64();
+    const int count0 = fp.class_count[0], count1 = fp.class_count[1], count2 = fp.class_count[2];
+    const int per_tile0 = (fp.n_passes + fp.class_ppi[0] - 1) / fp.class_ppi[0], per_tile1 = (fp.n_passes + fp.class_ppi[1] - 1) / fp.class_ppi[1],
+              per_tile2 = (fp.n_passes + fp.class_ppi[2] - 1) / fp.class_ppi[2];
+    const int items0 = count0 * per_tile0, items1 = count1 * per_tile1;
+    const int n_items = items0 + items1 + count2 * per_tile2;
     for (;;) {
         // every wave leaves through this test once the queue is drained
         unsigned fetched = 0;
         if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
         const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
-        if (item >= fp.n_items) break;
-        const int xb = item % fp.x_blocks;
-        const int y = (item / fp.x_blocks) % fp.rows;
-        const int chunk = item / (fp.x_blocks * fp.rows);
+        if (item >= n_items) break;
+        // item -> (class, tile rank, pass chunk): classes are contiguous in rank and in item index
+        int rel = item, rank0 = 0, cls = 0;
+        if (rel >= items0) { rel -= items0; rank0 = count0; cls = 1; if (rel >= items1) { rel -= items1; rank0 += count1; cls = 2; } }
+        const int per_tile = cls == 0 ? per_tile0 : cls == 1 ? per_tile1 : per_tile2;
+        const int ppi = fp.class_ppi[cls];
+        const int chunk = rel % per_tile;
+        const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
+        const int xb = tile % fp.x_blocks;
+        const int y = tile / fp.x_blocks;
         const int x = xb * kWave + lane;
         const bool valid = x < fp.traced_width;
-        const int k_end = min(fp.n_passes, (chunk + 1) * fp.chunk);
+        const int k_end = min(fp.n_passes, (chunk + 1) * ppi);
         float4 *rad = fp.radiance + (size_t)y * fp.width + x;
-        int k = chunk * fp.chunk;                                      // pass index relative to fp.first_pass
+        int k = chunk * ppi;                                           // pass index relative to fp.first_pass
         bool fresh = true;                                             // lane needs the primary ray of pass k
         PathState ps;
         ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
@@ -352,7 +389,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
                 fresh = false;
             }
             n_samples += __popcll(__ballot(alive && ps.bounces == 0));
-            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.o, ps.d, n_seg, n_mesh_seg);
+            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.bounces == 0, ps.o, ps.d, n_seg, n_mesh_seg, n_prim_mesh_seg);
             const bool hit = h.id >= 0 && h.t < kInfinity;
             n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
             if (alive) {
@@ -388,6 +425,11 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
         atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
         atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
+        atomicAdd(&fp.counters[6], (unsigned long long)n_prim_mesh_seg);
+        const unsigned long long span = wall_clock64() - t_start;
+        atomicAdd(&fp.counters[7], 1ull);
+        atomicAdd(&fp.counters[8], span);
+        atomicMax(&fp.counters[9], span);
     }
 }
 
@@ -421,6 +463,60 @@ __global__ void __launch_bounds__(kLdsBlock, WAVES_PER_SIMD) pt_trace_items_lds(
     LdsStore<SLOTS> st;
     st.A = ldsA + lane; st.B = ldsB + lane; st.C = ldsC + lane;
     trace_items_body<SLOTS>(sc, fp, st, lane);
+}
+
+// Scheduling pre-pass (no effect on results: a sample is a pure function of (pixel, pass)).  Sort key of a tile =
+// 65 x (pixels whose unjittered primary ray passes the root-AABB gate, i.e. brute-force mesh work on the first
+// segment and probably on later ones) + (other pixels that hit a scene primitive and so bounce at least once).
+constexpr int kMaxTileWeight = 65 * kWave;
+__global__ void __launch_bounds__(kWave) pt_tile_weights(SceneView sc, FrameParams fp)
+{
+    const int lane = threadIdx.x, tile = blockIdx.x;
+    const int xb = tile % fp.x_blocks, y = tile / fp.x_blocks;
+    const int x = xb * kWave + lane;
+    bool gate = false, other = false;
+    if (x < fp.traced_width) {
+        const float W = (float)fp.width, H = (float)fp.height;
+        const float X = -((((float)x / W - 0.5f) * W) / H), Y = (float)y / H - 0.5f;
+        const float *m = fp.iv;
+        const v3 d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
+        const v3 o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
+        if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), o, d);
+        for (int i = 0; i < sc.n_tris && !other; i++) {
+            const float4 p1 = sc.tri_p1[i], e1 = sc.tri_e1[i], e2 = sc.tri_e2[i];
+            float t, det;
+            other = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        }
+        for (int i = 0; i < sc.n_sph && !other; i++) {
+            const float4 sp = sc.sph[i];
+            float t; bool front;
+            other = hit_sphere(V(sp.x, sp.y, sp.z), sp.w, o, d, t, front);
+        }
+    }
+    const unsigned w = 65u * __popcll(__ballot(gate)) + __popcll(__ballot(other && !gate));
+    if (lane == 0) fp.weights[tile] = w;
+}
+
+// Counting sort of the tiles by descending weight: one workgroup, histogram and cursors in LDS.  The order inside
+// a weight class is whatever the atomics give; nothing depends on it.
+__global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, unsigned *order, int *class_count, int n_tiles)
+{
+    __shared__ unsigned hist[kMaxTileWeight + 1];
+    for (int i = threadIdx.x; i <= kMaxTileWeight; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) atomicAdd(&hist[min(weights[i], (unsigned)kMaxTileWeight)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int w = kMaxTileWeight; w >= 0; w--) {
+            const unsigned n = hist[w]; hist[w] = run; run += n;
+            if (w == 65) class_count[0] = (int)run;                    // keys >= 65: a mesh-gate pixel
+            if (w == 1) class_count[1] = (int)run - class_count[0];    // keys 1..64
+        }
+        class_count[2] = n_tiles - class_count[0] - class_count[1];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) order[atomicAdd(&hist[min(weights[i], (unsigned)kMaxTileWeight)], 1u)] = (unsigned)i;
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
@@ -459,8 +555,8 @@ __global__ void __launch_bounds__(kWave, 3) pt_primary_hits(SceneView sc, FrameP
     v3 o = V(0, 0, 0), d = V(0, 0, 1);
     uint32_t state = 0;
     if (valid) state = primary_ray(fp, x, y, fp.first_pass, o, d);
-    unsigned a = 0, b = 0;
-    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, o, d, a, b);
+    unsigned a = 0, b = 0, c = 0;
+    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, true, o, d, a, b, c);
     if (!valid) return;
     const size_t i = (size_t)y * fp.width + x;
     if (fp.out_ids) fp.out_ids[i] = h.id;
