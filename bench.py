@@ -32,9 +32,19 @@ FP32_VALU_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md "Peak FP32 (vector)"
 FLOP_TRI, FLOP_AABB, FLOP_SPHERE, FLOP_SHADE = 52, 27, 35, 150
 
 
-def algorithmic_flops(c, sc):
-    """FLOP the reference algorithm needs for the work the kernel counted (padded register slots are NOT counted)."""
+def brute_force_flops(c, sc):
+    """FLOP the reference's own algorithm (every mesh triangle behind the root-AABB gate, rt.comp:213-218) needs for
+    the segments the kernel counted (padded register slots are NOT counted)."""
     return (FLOP_TRI * (c["mesh_segments"] * len(sc.mesh_tris) + c["segments"] * len(sc.triangles))
+            + FLOP_SPHERE * c["segments"] * len(sc.spheres) + FLOP_AABB * c["segments"] + FLOP_SHADE * c["hits"])
+
+
+def executed_flops(c, sc):
+    """FLOP of the tests the kernel actually executed: for the BVH traversal the node (two slab tests each) and
+    triangle tests its counters report (BVH configs); for the brute-force kernels the same as above."""
+    if not c["bvh_node_visits"]:
+        return brute_force_flops(c, sc)
+    return (FLOP_TRI * (c["bvh_tri_tests"] + c["segments"] * len(sc.triangles)) + 2 * FLOP_AABB * c["bvh_node_visits"]
             + FLOP_SPHERE * c["segments"] * len(sc.spheres) + FLOP_AABB * c["segments"] + FLOP_SHADE * c["hits"])
 
 
@@ -62,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-brute-force", action="store_true", help="skip the extra (untimed) brute-force-kernel measurement")
     ap.add_argument("--passes-per-item", type=int, default=0, help="tuning: passes per work item (0 = library default)")
     ap.add_argument("--waves-per-cu", type=int, default=0, help="tuning: persistent waves per CU (0 = library default)")
     ap.add_argument("--variant", type=int, default=0, help="tuning: kernel variant (0 = library default)")
@@ -134,8 +145,30 @@ def main():
 
     c = r.counters()
     k_ms = float(np.mean(durs))
-    flops_per_launch = algorithmic_flops(c, sc) / a.steps
+    flops_per_launch = executed_flops(c, sc) / a.steps
+    bf_flops_per_launch = brute_force_flops(c, sc) / a.steps
     achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
+    kernel_name = {0: capi.load().pt_kernel_name().decode(), 1: "pt_trace_items", 5: "pt_trace_items_bvh"}.get(a.variant, "pt_trace_items_lds")
+
+    brute = None
+    if rank == 0 and world == 1 and not a.no_brute_force and kernel_name == "pt_trace_items_bvh":
+        # outside the timed region: the same render on the brute-force kernel (exact by construction), to show what the
+        # BVH buys and that both give the same image bit for bit
+        img = accum.clone()
+        r.set_tuning(0, 0, 0, 4)
+        r.reset_counters()
+        bd = []
+        for _ in range(3):
+            step()
+            bd.append(r.last_render_ms())
+        torch.cuda.synchronize()
+        bc = r.counters()
+        b_ms = float(np.mean(bd[1:]))
+        b_flops = brute_force_flops(bc, sc) / 3
+        brute = {"kernel": "pt_trace_items_lds", "kernel_ms": b_ms, "samples_per_s": W * H * SPP / (b_ms * 1e-3),
+                 "algorithmic_flop_per_launch": b_flops, "achieved_tflops": b_flops / (b_ms * 1e-3) / 1e12,
+                 "frac": b_flops / (b_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                 "image_bit_identical_to_bvh_path": bool(torch.equal(img.view(torch.int32), accum.view(torch.int32)))}
 
     if rank == 0:
         total_samples = W * H * SPP * world * a.steps
@@ -149,14 +182,21 @@ def main():
                        "parallelism": "spp-split x%d + 1 RCCL reduce/render" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": capi.load().pt_kernel_name().decode(), "kernel_ms": k_ms,
+                         "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_flop_per_launch": flops_per_launch,
-                         "note": "FP32 vector peak (FMA-counted); the path's parity contract forbids FMA contraction, so "
-                                 "unfused mul/add can reach at most 50% of this peak (tools/valu_rate.hip)",
+                         # the same segments traced the reference's way (every mesh triangle behind the gate)
+                         "brute_force_equivalent_flop_per_launch": bf_flops_per_launch,
+                         "brute_force_equivalent_tflops": bf_flops_per_launch / (k_ms * 1e-3) / 1e12,
+                         "note": "FP32 vector peak (FMA-counted); the parity contract forbids FMA contraction, so unfused mul/add "
+                                 "can reach at most 50% of it. achieved counts the tests EXECUTED (BVH node + triangle "
+                                 "tests from in-kernel counters); brute_force_equivalent_* prices the same segments the "
+                                 "reference's way; brute_force_kernel is that path measured",
                          "work_per_launch": {k: v / a.steps for k, v in c.items() if k != "wave_ticks_max"},
                          # mean wave span / longest wave span of the persistent grid (1.0 = no tail)
                          "wave_balance": c["wave_ticks_sum"] / max(1, c["waves"] * c["wave_ticks_max"])},
         }
+        if brute:
+            out["brute_force_kernel"] = brute
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, cam)
         print(json.dumps(out), flush=True)

@@ -56,6 +56,8 @@ typedef struct PtCounters {
     uint64_t waves;          /* persistent waves that ran                                       */
     uint64_t wave_ticks_sum; /* sum over waves of (last item done - wave start), 100 MHz ticks  */
     uint64_t wave_ticks_max; /* the longest such span: sum / (waves * max) = load balance       */
+    uint64_t bvh_node_visits;/* BVH variant: inner nodes fetched (two box tests each), per lane   */
+    uint64_t bvh_tri_tests;  /* BVH variant: ray-triangle tests executed, per lane               */
 } PtCounters;
 
 /* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */
@@ -124,8 +126,9 @@ int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
 /* Tuning knobs (0 = keep): passes per work item (default 2), the byte limit of the per-pass radiance
  * workspace [passes][H][W] float4 that bounds how many passes one launch covers (default 4 GiB), and the
  * number of persistent single-wave workgroups launched per CU (default 12 = 3 waves/SIMD), and the kernel
- * variant: 1 = mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = resident in a workgroup-shared LDS
- * image at 4 / 5 / 6 waves per SIMD (meshes of at most 704 triangles; larger meshes always use 1). */
+ * variant: 1 = brute force, mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = brute force, resident in a
+ * workgroup-shared LDS image at 4 / 5 / 6 waves per SIMD (meshes of at most 704 triangles; default for those),
+ * 5 = BVH traversal, one ray per lane (any mesh size; default for larger meshes; see DESIGN.md for its exactness). */
 int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
 /* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
 const char *pt_kernel_name(void);

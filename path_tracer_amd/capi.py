@@ -28,7 +28,8 @@ SYMBOLS = [
 
 class PtCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("mesh_segments", C.c_uint64), ("mesh_tri_tests", C.c_uint64), ("hits", C.c_uint64), ("wave_iterations", C.c_uint64),
-                ("primary_mesh_segments", C.c_uint64), ("waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64)]
+                ("primary_mesh_segments", C.c_uint64), ("waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64),
+                ("bvh_node_visits", C.c_uint64), ("bvh_tri_tests", C.c_uint64)]
 
 
 class PtError(RuntimeError):

@@ -3,6 +3,7 @@
 // device SoA/AoS images the kernels read, validates every index the kernels will dereference, and
 // launches on the context's stream.  No CPU rendering path exists here.
 #include "pt_kernels.hpp"
+#include "pt_bvh.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -17,6 +18,9 @@
 
 #ifndef PT_DEFAULT_LDS_VARIANT
 #define PT_DEFAULT_LDS_VARIANT 4
+#endif
+#ifndef PT_DEFAULT_VARIANT
+#define PT_DEFAULT_VARIANT 5
 #endif
 
 using namespace pt;
@@ -65,6 +69,8 @@ struct pt_ctx {
     float *accum = nullptr;            // own or external
     bool accum_external = false;
 
+    DevBuf bvh_nodes, bvh_tris;        // BVH over the mesh (pt_bvh.hpp); bvh_ok = usable (finite coordinates, depth within the stack)
+    bool bvh_ok = false; float bvh_scale = 0.0f; int bvh_depth = 0, bvh_n_nodes = 0;
     DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, counters;
     int n_mesh = 0, n_chunks = 0, n_tris = 0, n_sph = 0, n_mats = 0;
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
@@ -137,6 +143,7 @@ SceneView scene_view(const pt_ctx *c)
     s.n_tris = c->n_tris;
     s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
     s.mats = (const PtMaterial *)c->mats.p;
+    s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
     return s;
 }
 
@@ -156,6 +163,16 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     f.radiance = (float4 *)c->radiance.p;
     f.counters = (unsigned long long *)c->counters.p;
     return f;
+}
+
+// Kernel variant for the uploaded mesh.  Default: the BVH traversal whenever the builder accepted the mesh; brute
+// force from the LDS image (one register chunk) or from VGPRs otherwise, or when asked for through pt_set_tuning.
+int pick_variant(const pt_ctx *c)
+{
+    int variant = c->variant ? c->variant : PT_DEFAULT_VARIANT;
+    if (variant == 5 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
+    if (variant >= 2 && variant <= 4 && c->n_chunks != 1) variant = 1;    // the LDS image holds exactly one chunk
+    return variant;
 }
 
 int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
@@ -204,8 +221,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
             HIPCHK(c, hipGetLastError());
             c->order_dirty = false;
         }
-        int variant = c->variant ? c->variant : (c->n_chunks == 1 ? PT_DEFAULT_LDS_VARIANT : 1);
-        if (c->n_chunks != 1) variant = 1;      // the LDS image holds exactly one chunk
+        const int variant = pick_variant(c);
         HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(unsigned), c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
         if (variant == 1) {
@@ -217,6 +233,9 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         } else if (variant == 3) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 5);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+        } else if (variant == 5) {
+            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 4);
+            hipLaunchKernelGGL(pt_trace_items_bvh<kSlots>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
         } else {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
@@ -235,7 +254,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
 extern "C" {
 
 int pt_version(void) { return 1; }
-const char *pt_kernel_name(void) { return "pt_trace_items_lds"; }
+const char *pt_kernel_name(void) { return PT_DEFAULT_VARIANT == 5 ? "pt_trace_items_bvh" : "pt_trace_items_lds"; }
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -274,7 +293,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
@@ -355,6 +374,31 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     HIPCHK(c, c->mesh_e1.upload(e1.data(), e1.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->mesh_e2.upload(e2.data(), e2.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->mesh_nrm.upload(nr.data(), nr.size() * sizeof(float4), c->stream));
+    // BVH for the traversal variant: leaf-ordered (p1 | original index, e1, e2) records + 64-byte nodes
+    Bvh bvh;
+    bool finite = true; float scale = 0.0f;
+    for (int i = 0; i < n && finite; i++)
+        for (int k = 0; k < 3; k++) {
+            const float v[3] = {tris[i].p1[k], tris[i].p2[k], tris[i].p3[k]};
+            for (float x : v) { if (!std::isfinite(x)) finite = false; else scale = std::max(scale, std::fabs(x)); }
+        }
+    c->bvh_ok = false;
+    std::vector<float4> btris;
+    if (n > 0 && finite && scale < 1e18f) {
+        build_bvh(tris, n, bvh);
+        if (bvh.depth <= kBvhMaxDepth && (int)bvh.order.size() == n) {
+            btris.resize((size_t)3 * n);
+            for (int j = 0; j < n; j++) {
+                const int i = bvh.order[j];
+                float idf; std::memcpy(&idf, &i, 4);
+                btris[3 * (size_t)j] = make_float4(p1[i].x, p1[i].y, p1[i].z, idf);
+                btris[3 * (size_t)j + 1] = e1[i]; btris[3 * (size_t)j + 2] = e2[i];
+            }
+            HIPCHK(c, c->bvh_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), c->stream));
+            HIPCHK(c, c->bvh_tris.upload(btris.data(), btris.size() * sizeof(float4), c->stream));
+            c->bvh_ok = true; c->bvh_scale = scale; c->bvh_depth = bvh.depth; c->bvh_n_nodes = (int)bvh.nodes.size();
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));    // host staging vectors die here
     c->n_mesh = n; c->n_chunks = chunks; c->max_mat_mesh = maxm;
     for (int k = 0; k < 3; k++) { c->bmin[k] = n ? nodes[0].boundsMin[k] : 0.0f; c->bmax[k] = n ? nodes[0].boundsMax[k] : 0.0f; }
@@ -486,7 +530,10 @@ int pt_read_primary_hits(pt_ctx *c, int pass, int32_t *ids, float *t, float *dir
     FrameParams fp = frame_params(c, pass, 1, 0);
     fp.counters = nullptr;
     fp.out_ids = d_ids; fp.out_t = d_t; fp.out_dirs = d_dirs; fp.out_rng = d_rng;
-    hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
+    if (pick_variant(c) == 5)
+        hipLaunchKernelGGL(pt_primary_hits_bvh<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
+    else
+        hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
     TRY(hipGetLastError());
     if (ids) TRY(hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (t) TRY(hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -507,6 +554,7 @@ int pt_get_counters(pt_ctx *c, PtCounters *out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3]; out->hits = v[4]; out->wave_iterations = v[5];
     out->primary_mesh_segments = v[6]; out->waves = v[7]; out->wave_ticks_sum = v[8]; out->wave_ticks_max = v[9];
+    out->bvh_node_visits = v[10]; out->bvh_tri_tests = v[11];
     return PT_OK;
 }
 
@@ -538,7 +586,7 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;
-    if (variant < 0 || variant > 4) return fail(c, PT_E_INVALID, "variant outside [0,4]");
+    if (variant < 0 || variant > 5) return fail(c, PT_E_INVALID, "variant outside [0,5]");
     if (variant) c->variant = variant;
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
     if (waves_per_cu) c->waves_per_cu = waves_per_cu;

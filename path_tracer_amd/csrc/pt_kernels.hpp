@@ -29,6 +29,7 @@ namespace pt {
 constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
 constexpr int kNumCounters = 16;
+constexpr int kBvhStack = 40;                // == kBvhMaxDepth (pt_bvh.hpp): per-lane traversal stack entries
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
 struct SceneView {
@@ -45,6 +46,10 @@ struct SceneView {
     const uint32_t *sph_mat;
     int n_sph;
     const PtMaterial *mats;   // SSBO 3
+    // BVH over the mesh triangles (pt_bvh.hpp), used by the traversal variant
+    const float4 *bvh_nodes;  // 4 x float4 per inner node: both child boxes + child codes
+    const float4 *bvh_tris;   // 3 x float4 per triangle in leaf order: (p1, bits(original index)), e1, e2
+    float bvh_scale;          // largest |coordinate| of the mesh (for the traversal's safety margin)
 };
 
 struct FrameParams {
@@ -66,7 +71,7 @@ struct FrameParams {
     unsigned *weights;        // per-tile sort key, written by pt_tile_weights
     int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
-                                    // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span
+                                    // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span [10] BVH node visits [11] BVH triangle tests
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
 };
@@ -142,6 +147,7 @@ __device__ __forceinline__ float wave_min_to_lane63(float v)
 //            the loop needs: one wave issues a VALU op only every ~5 cycles (tools/slot_bench.hip).
 template <int SLOTS>
 struct RegStore {
+    static constexpr bool is_bvh = false;
     TriRegs<SLOTS> T;
     const float *soa; int lane; bool resident;
     __device__ __forceinline__ void init(const SceneView &sc, int lane_)
@@ -158,6 +164,7 @@ struct RegStore {
 
 template <int SLOTS>
 struct LdsStore {
+    static constexpr bool is_bvh = false;
     const float4 *A, *B; const float *C;      // LDS images, already offset by this lane: [slot][64]
     __device__ __forceinline__ void begin_chunk(int) {}
     __device__ __forceinline__ void get(int s, v3 &p1, v3 &e1, v3 &e2) const
@@ -223,13 +230,102 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, Store &st, int
     }
 }
 
+// ---- BVH traversal (one ray per lane) ----------------------------------------------------------------------
+// Finds the same (t, id) as the brute-force scan: every triangle whose test can pass is visited, the test itself is
+// the reference arithmetic (hit_triangle_t), and the winner is the lexicographic minimum of (t, original index).
+// Only the SKIPPING is ours, so its arithmetic is free to use FMAs; it must merely be conservative:
+//  * boxes are grown per ray by delta = 4e-6 * (|o|_1 + mesh scale) (~30 ulp of the largest coordinate in play): the
+//    reference's float test can accept a ray that geometrically misses a triangle by rounding noise of that size;
+//  * a subtree is pruned against the best hit only if its entry distance exceeds best_t * 1.001 + delta, since the
+//    reference's computed t carries a relative error that grows with 1/sin(angle between ray and triangle);
+//  * min/max are IEEE minNum/maxNum, so a 0 * inf = NaN slab (ray parallel to an axis and lying on the slab plane)
+//    imposes no constraint.
+// Not covered by construction: a ray within rounding noise of being COPLANAR with a triangle it misses in-plane (the
+// reference's u, v are then noise / noise); see DESIGN.md.
+struct BvhStore {
+    static constexpr bool is_bvh = true;
+    unsigned *stack;          // LDS, already offset by this lane; entry e at stack[e * 64]
+    __device__ __forceinline__ void begin_chunk(int) {}
+};
+
+__device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 olo, v3 ohi, v3 inv,
+                                          float &t0, float &t1)
+{
+    // ((b -+ delta) - o) * inv for both planes of each axis, with olo = o + delta, ohi = o - delta; conservative, not
+    // reference arithmetic.  0 * inf = NaN (ray parallel to the axis, origin on the grown plane) drops out of minNum/maxNum.
+    const float x1 = (mnx - olo.x) * inv.x, x2 = (mxx - ohi.x) * inv.x;
+    const float y1 = (mny - olo.y) * inv.y, y2 = (mxy - ohi.y) * inv.y;
+    const float z1 = (mnz - olo.z) * inv.z, z2 = (mxz - ohi.z) * inv.z;
+    t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fmaxf(__builtin_fminf(z1, z2), 0.0f));
+    t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2)) * 1.000001f;
+}
+
+__device__ __forceinline__ void bvh_closest(const SceneView &sc, BvhStore &st, bool gate, v3 o, v3 d, float &best_t, int &best_id,
+                                            unsigned &n_nodes, unsigned &n_tests)
+{
+    if (!gate) return;
+    const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const float delta = 4e-6f * ((fabsf(o.x) + fabsf(o.y)) + (fabsf(o.z) + sc.bvh_scale));
+    const v3 olo = V(o.x + delta, o.y + delta, o.z + delta), ohi = V(o.x - delta, o.y - delta, o.z - delta);
+    unsigned *stk = st.stack;
+    int sp = 0, cur = 0;
+    for (;;) {
+        const float4 *n = sc.bvh_nodes + 4 * (size_t)cur;
+        const float4 a = n[0], b = n[1], c = n[2];
+        const float4 kf = n[3];
+        const int kl = __float_as_int(kf.x), kr = __float_as_int(kf.y);
+        n_nodes++;
+        float l0, l1, r0, r1;
+        slab_test(a.x, a.y, a.z, a.w, b.x, b.y, olo, ohi, inv, l0, l1);
+        slab_test(b.z, b.w, c.x, c.y, c.z, c.w, olo, ohi, inv, r0, r1);
+        const float lim = fmaf(best_t, 1.001f, delta);
+        const bool hl = l0 <= l1 && l0 <= lim, hr = r0 <= r1 && r0 <= lim;
+        int next;
+        if (hl && hr) {
+            const bool left_first = l0 <= r0;
+            next = left_first ? kl : kr;
+            stk[sp * kWave] = (unsigned)(left_first ? kr : kl);
+            sp++;
+        } else if (hl) {
+            next = kl;
+        } else if (hr) {
+            next = kr;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            next = (int)stk[sp * kWave];
+        }
+        bool done = false;
+        while (next < 0) {
+            const int code = ~next, first = code >> 3, cnt = (code & 7) + 1;
+            for (int i = 0; i < cnt; i++) {
+                const float4 *tp = sc.bvh_tris + 3 * (size_t)(first + i);
+                const float4 p1 = tp[0], e1 = tp[1], e2 = tp[2];
+                float t, det;
+                bool bad = false;
+                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, bad);
+                if (__builtin_expect(bad, 0)) has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+                const int id = __float_as_int(p1.w);
+                n_tests++;
+                if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+            }
+            if (sp == 0) { done = true; break; }
+            sp--;
+            next = (int)stk[sp * kWave];
+        }
+        if (done) break;
+        cur = next;
+    }
+}
+
 struct Hit { int id; float t; bool front; v3 normal; uint32_t mat; };
 
 // CalculateRay (rt.comp:204-232) for the pixel of this lane; `alive` lanes take part, the mesh part is
 // wave-cooperative.  Canonical ids: mesh i | n_mesh + i | n_mesh + n_tris + i | -1.
 template <int SLOTS, class Store>
 __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int lane, bool alive, bool primary, v3 o, v3 d,
-                                             unsigned &n_seg, unsigned &n_mesh_seg, unsigned &n_prim_mesh_seg)
+                                             unsigned &n_seg, unsigned &n_mesh_seg, unsigned &n_prim_mesh_seg,
+                                             unsigned &n_bvh_nodes, unsigned &n_bvh_tests)
 {
     Hit h;
     h.id = -1; h.t = kInfinity; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
@@ -240,7 +336,11 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int
     n_seg += __popcll(__ballot(alive));
     n_mesh_seg += __popcll(gate_mask);
     n_prim_mesh_seg += __popcll(__ballot(gate && primary));
-    if (gate_mask) mesh_closest<SLOTS>(sc, st, lane, gate_mask, o, d, h.t, h.id);
+    if constexpr (Store::is_bvh) {
+        bvh_closest(sc, st, gate, o, d, h.t, h.id, n_bvh_nodes, n_bvh_tests);
+    } else {
+        if (gate_mask) mesh_closest<SLOTS>(sc, st, lane, gate_mask, o, d, h.t, h.id);
+    }
     if (!alive) return h;
 
     float win_det = 0.0f;
@@ -350,6 +450,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const size_t plane = (size_t)fp.width * fp.height;
     unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
+    unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
     const unsigned long long t_start = wall_clock64();
     const int count0 = fp.class_count[0], count1 = fp.class_count[1], count2 = fp.class_count[2];
     const int per_tile0 = (fp.n_passes + fp.class_ppi[0] - 1) / fp.class_ppi[0], per_tile1 = (fp.n_passes + fp.class_ppi[1] - 1) / fp.class_ppi[1],
@@ -389,7 +490,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
                 fresh = false;
             }
             n_samples += __popcll(__ballot(alive && ps.bounces == 0));
-            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.bounces == 0, ps.o, ps.d, n_seg, n_mesh_seg, n_prim_mesh_seg);
+            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.bounces == 0, ps.o, ps.d, n_seg, n_mesh_seg, n_prim_mesh_seg, n_bvh_nodes, n_bvh_tests);
             const bool hit = h.id >= 0 && h.t < kInfinity;
             n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
             if (alive) {
@@ -418,11 +519,17 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
             }
         }
     }
+    if constexpr (Store::is_bvh) {
+        if (fp.counters) {
+            for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); }
+            if (lane == 0) { atomicAdd(&fp.counters[10], (unsigned long long)n_bvh_nodes); atomicAdd(&fp.counters[11], (unsigned long long)n_bvh_tests); }
+        }
+    }
     if (lane == 0 && fp.counters) {
         atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
         atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
         atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
-        atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
+        if constexpr (!Store::is_bvh) atomicAdd(&fp.counters[3], (unsigned long long)n_mesh_seg * sc.n_chunks * (kWave * SLOTS));
         atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
         atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
         atomicAdd(&fp.counters[6], (unsigned long long)n_prim_mesh_seg);
@@ -519,6 +626,18 @@ __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, u
     for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) order[atomicAdd(&hist[min(weights[i], (unsigned)kMaxTileWeight)], 1u)] = (unsigned)i;
 }
 
+// BVH traversal variant (any mesh size; the default for meshes of more than one register chunk): persistent 4-wave
+// workgroups, one ray per lane, per-lane traversal stack in LDS (kBvhStack entries x 64 lanes x 4 waves = 40 KB).
+template <int SLOTS>
+__global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp)
+{
+    __shared__ unsigned stack[kBvhStack * kLdsBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    BvhStore st;
+    st.stack = stack + wave * (kBvhStack * kWave) + lane;
+    trace_items_body<SLOTS>(sc, fp, st, lane);
+}
+
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
 // (sum_mode: plain sum for the multi-GPU sample split).  One thread per traced pixel.
 __global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
@@ -543,26 +662,40 @@ __global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
 }
 
 // Test-only probe: primary ray + CalculateRay per pixel (pt_read_primary_hits).
-template <int SLOTS>
-__global__ void __launch_bounds__(kWave, 3) pt_primary_hits(SceneView sc, FrameParams fp)
+template <int SLOTS, class Store>
+__device__ __forceinline__ void primary_hits_body(const SceneView &sc, const FrameParams &fp, Store &st, int lane, int tile)
 {
-    const int lane = threadIdx.x;
-    const int xb = blockIdx.x % fp.x_blocks, y = blockIdx.x / fp.x_blocks;
+    const int xb = tile % fp.x_blocks, y = tile / fp.x_blocks;
     const int x = xb * kWave + lane;
     const bool valid = x < fp.traced_width;
-    RegStore<SLOTS> st;
-    st.init(sc, lane);
     v3 o = V(0, 0, 0), d = V(0, 0, 1);
     uint32_t state = 0;
     if (valid) state = primary_ray(fp, x, y, fp.first_pass, o, d);
-    unsigned a = 0, b = 0, c = 0;
-    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, true, o, d, a, b, c);
+    unsigned a = 0, b = 0, c = 0, e = 0, f = 0;
+    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, true, o, d, a, b, c, e, f);
     if (!valid) return;
     const size_t i = (size_t)y * fp.width + x;
     if (fp.out_ids) fp.out_ids[i] = h.id;
     if (fp.out_t) fp.out_t[i] = h.t;
     if (fp.out_dirs) { fp.out_dirs[3 * i] = d.x; fp.out_dirs[3 * i + 1] = d.y; fp.out_dirs[3 * i + 2] = d.z; }
     if (fp.out_rng) fp.out_rng[i] = state;
+}
+
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave, 3) pt_primary_hits(SceneView sc, FrameParams fp)
+{
+    RegStore<SLOTS> st;
+    st.init(sc, threadIdx.x);
+    primary_hits_body<SLOTS>(sc, fp, st, threadIdx.x, blockIdx.x);
+}
+
+template <int SLOTS>
+__global__ void __launch_bounds__(kWave) pt_primary_hits_bvh(SceneView sc, FrameParams fp)
+{
+    __shared__ unsigned stack[kBvhStack * kWave];
+    BvhStore st;
+    st.stack = stack + threadIdx.x;
+    primary_hits_body<SLOTS>(sc, fp, st, threadIdx.x, blockIdx.x);
 }
 
 __global__ void pt_scale_kernel(float4 *accum, size_t n, float scale, int set_alpha_one)

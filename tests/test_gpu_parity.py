@@ -168,8 +168,10 @@ def test_trailing_pixels_are_not_traced(capi, cameras, scenes):
     r.close()
 
 
-def test_multi_chunk_mesh_and_tie_breaking(capi, cameras):
-    """mesh larger than one register-resident chunk (704 tris) + duplicated triangles (equal t: lowest index wins)"""
+@pytest.mark.parametrize("variant", [0, 1, 5])
+def test_multi_chunk_mesh_and_tie_breaking(capi, cameras, variant):
+    """mesh larger than one register-resident chunk (704 tris) + duplicated triangles (equal t: lowest index wins);
+    variant 0 = library default (BVH traversal for a mesh of this size), 1 = brute force, 5 = BVH"""
     import oracle_py as O
     from path_tracer_amd import scene as S
     m = S.heightfield_mesh(24, 1)                      # 1152 triangles -> 2 chunks
@@ -179,6 +181,8 @@ def test_multi_chunk_mesh_and_tie_breaking(capi, cameras):
     cam = S.Camera(position=np.array([0.2, 1.6, 2.2], np.float32), yaw=95.0, pitch=35.0).UpdateView()
     W, H = 128, 72
     r = make(capi, sc, cam, W, H, 5)
+    if variant:
+        r.set_tuning(0, 0, 0, variant)
     ids, t, dirs, st = r.read_primary_hits(1)
     o = O.Oracle(sc, cam, W, H, 5)
     oi, ot, od, os_ = o.primary_hits(1)
@@ -231,9 +235,9 @@ def test_error_behaviour(capi, cameras, scenes):
     L.pt_destroy(h)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 def test_kernel_variants_are_bit_identical(capi, variant, meta, cameras, scenes):
-    """VGPR-resident and LDS-resident triangle stores must give the reference image (config 1 CRC) alike"""
+    """VGPR-resident and LDS-resident brute force and the BVH traversal must give the reference image (config 1 CRC) alike"""
     r = make(capi, scenes["default"], cameras["bench"], 640, 360, 4)
     r.set_tuning(0, 0, 0, variant)
     r.render(1, 16)
@@ -265,3 +269,23 @@ def test_workspace_batches_and_item_sizes_do_not_change_results(capi, cameras, s
             assert launches == 4
         r.close()
     ref.close()
+
+
+def test_bvh_heightfield_8k_triangles_vs_oracle(capi, cameras):
+    """config-3-shaped mesh (tessellated height field) small enough for the brute-force oracle: the BVH traversal
+    (library default for this size) must reproduce it bit for bit, primary rays and bounced paths"""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    m = S.heightfield_mesh(64, 1)                      # 8192 triangles
+    sc = S.default_scene(m)
+    cam = S.Camera(position=np.array([0.2, 1.6, 2.2], np.float32), yaw=95.0, pitch=35.0).UpdateView()
+    W, H = 192, 104
+    r = make(capi, sc, cam, W, H, 6)
+    r.reset_counters()
+    r.render(1, 4)
+    c = r.counters()
+    assert c["bvh_tri_tests"] > 0 and c["mesh_tri_tests"] == 0, "the BVH kernel did not run"
+    assert c["bvh_tri_tests"] < 0.02 * c["mesh_segments"] * len(m.tris), "the BVH culls nothing"
+    want = O.Oracle(sc, cam, W, H, 6).render(1, 4)
+    assert n_diff_pixels(r.read_accum(), want) == 0
+    r.close()
