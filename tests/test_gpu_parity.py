@@ -289,3 +289,41 @@ def test_bvh_heightfield_8k_triangles_vs_oracle(capi, cameras):
     want = O.Oracle(sc, cam, W, H, 6).render(1, 4)
     assert n_diff_pixels(r.read_accum(), want) == 0
     r.close()
+
+
+def test_config3_1m_triangle_mesh_1080p_windows_vs_oracle(capi):
+    """BASELINE.json configs[2]: ~1M-triangle tessellated height field at 1080p through the BVH traversal.  The
+    brute-force oracle costs ~1M ray-triangle tests per segment, so it checks two small windows (bit-exact, bounced
+    paths included); the whole frame is checked for determinism and against the brute-force HIP kernel on a strip."""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    m = S.heightfield_mesh(708, 3)
+    assert len(m.tris) == 1002528
+    sc = S.default_scene(m)
+    cam = S.Camera(position=np.array([0.2, 1.6, 2.2], np.float32), yaw=95.0, pitch=35.0).UpdateView()
+    W, H, B, SPP = 1920, 1080, 4, 2
+    r = make(capi, sc, cam, W, H, B)
+    r.reset_counters()
+    r.render(1, SPP)
+    full = r.read_accum()
+    c = r.counters()
+    assert c["samples"] == W * H * SPP and c["bvh_tri_tests"] > 0 and c["mesh_segments"] > 0.2 * c["samples"]
+    assert c["bvh_tri_tests"] < 50 * c["mesh_segments"], "more than 50 of 1M triangles tested per ray"
+    r.reset()
+    r.render(1, 1)
+    r.render(2, 1)
+    assert crc(r.read_accum()) == crc(full)
+    o = O.Oracle(sc, cam, W, H, B)
+    for (x0, y0, w, h) in ((940, 500, 24, 4), (300, 700, 16, 4)):
+        want = o.render_region(1, SPP, x0, y0, w, h)
+        assert n_diff_pixels(full[y0:y0 + h, x0:x0 + w], want) == 0, (x0, y0)
+    r.close()
+    # brute-force HIP kernel (1424 register chunks per gate-passing ray) on a small frame with the same camera
+    Ws, Hs = 64, 40
+    a = make(capi, sc, cam, Ws, Hs, B)
+    a.render(1, 1)
+    b = make(capi, sc, cam, Ws, Hs, B)
+    b.set_tuning(0, 0, 0, 1)
+    b.render(1, 1)
+    assert bits_equal(a.read_accum(), b.read_accum())
+    a.close(); b.close()

@@ -18,10 +18,14 @@ ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
-sc = {"default": S.default_scene, "mixed": S.mixed_scene}[a.scene]()
+import time
+if a.scene.startswith("hf"):
+    t0 = time.time(); sc = S.default_scene(S.heightfield_mesh(int(a.scene[2:]), 3)); print("mesh built in %.1f s, %d triangles" % (time.time() - t0, len(sc.mesh_tris)), flush=True)
+else:
+    sc = {"default": S.default_scene, "mixed": S.mixed_scene}[a.scene]()
 cam = S.Camera(position=a.cam[:3], yaw=a.cam[3], pitch=a.cam[4]); cam.UpdateView()
 r = capi.Renderer(a.size[0], a.size[1])
-r.upload_scene(sc); r.SetUniformCamera(cam); r.SetUniform1i("maxBounces", a.bounces)
+t0 = time.time(); r.upload_scene(sc); print("upload (incl. BVH build) %.2f s" % (time.time() - t0), flush=True); r.SetUniformCamera(cam); r.SetUniform1i("maxBounces", a.bounces)
 if a.chunk or a.waves or a.variant:
     r.set_tuning(a.chunk, 0, a.waves, a.variant)
 ms = []
