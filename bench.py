@@ -148,10 +148,10 @@ def main():
     flops_per_launch = executed_flops(c, sc) / a.steps
     bf_flops_per_launch = brute_force_flops(c, sc) / a.steps
     achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
-    kernel_name = {0: capi.load().pt_kernel_name().decode(), 1: "pt_trace_items", 5: "pt_trace_items_bvh"}.get(a.variant, "pt_trace_items_lds")
+    kernel_name = {0: capi.load().pt_kernel_name().decode(), 1: "pt_trace_items", 5: "pt_trace_items_bvh", 6: "pt_trace_items_bvh_lds"}.get(a.variant, "pt_trace_items_lds")
 
     brute = None
-    if rank == 0 and world == 1 and not a.no_brute_force and kernel_name == "pt_trace_items_bvh":
+    if rank == 0 and world == 1 and not a.no_brute_force and kernel_name.startswith("pt_trace_items_bvh"):
         # outside the timed region: the same render on the brute-force kernel (exact by construction), to show what the
         # BVH buys and that both give the same image bit for bit
         img = accum.clone()
@@ -191,7 +191,7 @@ def main():
                                  "can reach at most 50% of it. achieved counts the tests EXECUTED (BVH node + triangle "
                                  "tests from in-kernel counters); brute_force_equivalent_* prices the same segments the "
                                  "reference's way; brute_force_kernel is that path measured",
-                         "work_per_launch": {k: v / a.steps for k, v in c.items() if k != "wave_ticks_max"},
+                         "work_per_launch": {k: v / a.steps for k, v in c.items() if k not in ("wave_ticks_max", "phase_cycles")},
                          # mean wave span / longest wave span of the persistent grid (1.0 = no tail)
                          "wave_balance": c["wave_ticks_sum"] / max(1, c["waves"] * c["wave_ticks_max"])},
         }

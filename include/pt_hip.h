@@ -58,6 +58,7 @@ typedef struct PtCounters {
     uint64_t wave_ticks_max; /* the longest such span: sum / (waves * max) = load balance       */
     uint64_t bvh_node_visits;/* BVH variant: inner nodes fetched (two box tests each), per lane   */
     uint64_t bvh_tri_tests;  /* BVH variant: ray-triangle tests executed, per lane               */
+    uint64_t phase_cycles[4];/* diagnostic builds (-DPT_PHASE_TIMERS=1): wave cycles in ray generation / closest hit / shading / (part of closest hit) mesh traversal; else 0 */
 } PtCounters;
 
 /* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */
@@ -128,7 +129,8 @@ int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
  * number of persistent single-wave workgroups launched per CU (default 12 = 3 waves/SIMD), and the kernel
  * variant: 1 = brute force, mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = brute force, resident in a
  * workgroup-shared LDS image at 4 / 5 / 6 waves per SIMD (meshes of at most 704 triangles; default for those),
- * 5 = BVH traversal, one ray per lane (any mesh size; default for larger meshes; see DESIGN.md for its exactness). */
+ * 5 = BVH traversal, one ray per lane, BVH in global memory (any mesh size), 6 = the same with the BVH staged into
+ * LDS (default; falls back to 5 when nodes + triangles + stacks exceed 80 KB; see DESIGN.md for its exactness). */
 int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
 /* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
 const char *pt_kernel_name(void);

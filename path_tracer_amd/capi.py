@@ -29,7 +29,7 @@ SYMBOLS = [
 class PtCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("mesh_segments", C.c_uint64), ("mesh_tri_tests", C.c_uint64), ("hits", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("primary_mesh_segments", C.c_uint64), ("waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64),
-                ("bvh_node_visits", C.c_uint64), ("bvh_tri_tests", C.c_uint64)]
+                ("bvh_node_visits", C.c_uint64), ("bvh_tri_tests", C.c_uint64), ("phase_cycles", C.c_uint64 * 4)]
 
 
 class PtError(RuntimeError):
@@ -170,7 +170,9 @@ class Renderer:
     def counters(self):
         c = PtCounters()
         self._ck(self.L.pt_get_counters(self.h, C.byref(c)))
-        return {name: int(getattr(c, name)) for name, _ in PtCounters._fields_}
+        d = {name: int(getattr(c, name)) for name, _ in PtCounters._fields_ if name != "phase_cycles"}
+        d["phase_cycles"] = [int(v) for v in c.phase_cycles]
+        return d
 
     def reset_counters(self):
         self._ck(self.L.pt_reset_counters(self.h))

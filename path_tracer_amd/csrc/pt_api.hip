@@ -20,7 +20,7 @@
 #define PT_DEFAULT_LDS_VARIANT 4
 #endif
 #ifndef PT_DEFAULT_VARIANT
-#define PT_DEFAULT_VARIANT 5
+#define PT_DEFAULT_VARIANT 6
 #endif
 
 using namespace pt;
@@ -165,12 +165,20 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     return f;
 }
 
+// LDS the LDS-resident BVH kernel needs per 512-thread workgroup; two workgroups must fit in a CU's 160 KB.
+constexpr size_t kBvhLdsLimit = 80 * 1024;
+size_t bvh_lds_bytes(const pt_ctx *c)
+{
+    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (size_t)(c->bvh_depth + 1) * 4 * kBvhLdsBlock;
+}
+
 // Kernel variant for the uploaded mesh.  Default: the BVH traversal whenever the builder accepted the mesh; brute
 // force from the LDS image (one register chunk) or from VGPRs otherwise, or when asked for through pt_set_tuning.
 int pick_variant(const pt_ctx *c)
 {
     int variant = c->variant ? c->variant : PT_DEFAULT_VARIANT;
-    if (variant == 5 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
+    if ((variant == 5 || variant == 6) && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
+    if (variant == 6 && bvh_lds_bytes(c) > kBvhLdsLimit) variant = 5;     // too large for two workgroups per CU
     if (variant >= 2 && variant <= 4 && c->n_chunks != 1) variant = 1;    // the LDS image holds exactly one chunk
     return variant;
 }
@@ -233,6 +241,11 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         } else if (variant == 3) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 5);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+        } else if (variant == 6) {
+            const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
+            const size_t lds = bvh_lds_bytes(c);
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_bvh_lds<kSlots>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(pt_trace_items_bvh_lds<kSlots>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
         } else if (variant == 5) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 4);
             hipLaunchKernelGGL(pt_trace_items_bvh<kSlots>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
@@ -254,7 +267,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
 extern "C" {
 
 int pt_version(void) { return 1; }
-const char *pt_kernel_name(void) { return PT_DEFAULT_VARIANT == 5 ? "pt_trace_items_bvh" : "pt_trace_items_lds"; }
+const char *pt_kernel_name(void) { return PT_DEFAULT_VARIANT >= 5 ? "pt_trace_items_bvh_lds" : "pt_trace_items_lds"; }
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -530,7 +543,7 @@ int pt_read_primary_hits(pt_ctx *c, int pass, int32_t *ids, float *t, float *dir
     FrameParams fp = frame_params(c, pass, 1, 0);
     fp.counters = nullptr;
     fp.out_ids = d_ids; fp.out_t = d_t; fp.out_dirs = d_dirs; fp.out_rng = d_rng;
-    if (pick_variant(c) == 5)
+    if (pick_variant(c) >= 5)
         hipLaunchKernelGGL(pt_primary_hits_bvh<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
     else
         hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
@@ -555,6 +568,7 @@ int pt_get_counters(pt_ctx *c, PtCounters *out)
     out->samples = v[0]; out->segments = v[1]; out->mesh_segments = v[2]; out->mesh_tri_tests = v[3]; out->hits = v[4]; out->wave_iterations = v[5];
     out->primary_mesh_segments = v[6]; out->waves = v[7]; out->wave_ticks_sum = v[8]; out->wave_ticks_max = v[9];
     out->bvh_node_visits = v[10]; out->bvh_tri_tests = v[11];
+    out->phase_cycles[0] = v[12]; out->phase_cycles[1] = v[13]; out->phase_cycles[2] = v[14]; out->phase_cycles[3] = v[15];
     return PT_OK;
 }
 
@@ -586,7 +600,7 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;
-    if (variant < 0 || variant > 5) return fail(c, PT_E_INVALID, "variant outside [0,5]");
+    if (variant < 0 || variant > 6) return fail(c, PT_E_INVALID, "variant outside [0,6]");
     if (variant) c->variant = variant;
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
     if (waves_per_cu) c->waves_per_cu = waves_per_cu;

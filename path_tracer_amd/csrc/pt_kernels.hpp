@@ -110,6 +110,17 @@ __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_fl
 // Copy a wave-uniform value into a VGPR and hide its uniformity from the compiler.  On gfx950 a VALU instruction with
 // an SGPR source issues in 4 SIMD cycles, the same mul/add/sub/fma with VGPR sources in 2 (tools/valu_mix.hip), so the
 // broadcast ray lives in VGPRs: 6 moves per ray instead of 12 slow operand reads per triangle slot.
+// Optional per-phase cycle accounting (s_memtime per wave, summed into counters 12..15): diagnostic builds only.
+#ifndef PT_PHASE_TIMERS
+#define PT_PHASE_TIMERS 0
+#endif
+#if PT_PHASE_TIMERS
+#define PT_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PT_ACC(acc, a, b) acc += (b) - (a)
+#else
+#define PT_TICK(var)
+#define PT_ACC(acc, a, b)
+#endif
 #ifndef PT_RAY_IN_VGPR
 #define PT_RAY_IN_VGPR 1
 #endif
@@ -242,10 +253,48 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, Store &st, int
 //    imposes no constraint.
 // Not covered by construction: a ray within rounding noise of being COPLANAR with a triangle it misses in-plane (the
 // reference's u, v are then noise / noise); see DESIGN.md.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const f4v lds_cf4v;
+
+// BVH in global memory (any size; served by L1/L2) ...
 struct BvhStore {
     static constexpr bool is_bvh = true;
     unsigned *stack;          // LDS, already offset by this lane; entry e at stack[e * 64]
+    const float4 *nodes, *tris;
     __device__ __forceinline__ void begin_chunk(int) {}
+    __device__ __forceinline__ void node(int i, float4 &a, float4 &b, float4 &c, int &kl, int &kr) const
+    {
+        const float4 *n = nodes + 4 * (size_t)i;
+        a = n[0]; b = n[1]; c = n[2];
+        const float4 k = n[3];
+        kl = __float_as_int(k.x); kr = __float_as_int(k.y);
+    }
+    __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
+    {
+        const float4 *t = tris + 3 * (size_t)j;
+        p1 = t[0]; e1 = t[1]; e2 = t[2];
+    }
+};
+// ... or copied into the workgroup's LDS (meshes whose nodes + triangles fit beside the stacks): a dependent node
+// fetch then costs ~100 cycles instead of an L2 round trip, and the traversal is a chain of them.
+struct BvhLdsStore {
+    static constexpr bool is_bvh = true;
+    unsigned *stack;
+    lds_cf4v *nodes, *tris;
+    __device__ __forceinline__ void begin_chunk(int) {}
+    static __device__ __forceinline__ float4 f4(const f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ void node(int i, float4 &a, float4 &b, float4 &c, int &kl, int &kr) const
+    {
+        lds_cf4v *n = nodes + 4 * i;
+        a = f4(n[0]); b = f4(n[1]); c = f4(n[2]);
+        const f4v k = n[3];
+        kl = __float_as_int(k.x); kr = __float_as_int(k.y);
+    }
+    __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
+    {
+        lds_cf4v *t = tris + 3 * j;
+        p1 = f4(t[0]); e1 = f4(t[1]); e2 = f4(t[2]);
+    }
 };
 
 __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 olo, v3 ohi, v3 inv,
@@ -260,7 +309,8 @@ __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float
     t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2)) * 1.000001f;
 }
 
-__device__ __forceinline__ void bvh_closest(const SceneView &sc, BvhStore &st, bool gate, v3 o, v3 d, float &best_t, int &best_id,
+template <class Store>
+__device__ __forceinline__ void bvh_closest(const SceneView &sc, Store &st, bool gate, v3 o, v3 d, float &best_t, int &best_id,
                                             unsigned &n_nodes, unsigned &n_tests)
 {
     if (!gate) return;
@@ -270,10 +320,9 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, BvhStore &st, b
     unsigned *stk = st.stack;
     int sp = 0, cur = 0;
     for (;;) {
-        const float4 *n = sc.bvh_nodes + 4 * (size_t)cur;
-        const float4 a = n[0], b = n[1], c = n[2];
-        const float4 kf = n[3];
-        const int kl = __float_as_int(kf.x), kr = __float_as_int(kf.y);
+        float4 a, b, c;
+        int kl, kr;
+        st.node(cur, a, b, c, kl, kr);
         n_nodes++;
         float l0, l1, r0, r1;
         slab_test(a.x, a.y, a.z, a.w, b.x, b.y, olo, ohi, inv, l0, l1);
@@ -299,8 +348,8 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, BvhStore &st, b
         while (next < 0) {
             const int code = ~next, first = code >> 3, cnt = (code & 7) + 1;
             for (int i = 0; i < cnt; i++) {
-                const float4 *tp = sc.bvh_tris + 3 * (size_t)(first + i);
-                const float4 p1 = tp[0], e1 = tp[1], e2 = tp[2];
+                float4 p1, e1, e2;
+                st.tri(first + i, p1, e1, e2);
                 float t, det;
                 bool bad = false;
                 bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, bad);
@@ -320,12 +369,62 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, BvhStore &st, b
 
 struct Hit { int id; float t; bool front; v3 normal; uint32_t mat; };
 
+// Scene triangles (SSBO 5) then spheres (SSBO 4), in order, strict `t < closest` (rt.comp:219-230), starting from
+// the closest hit found so far (t, id).
+__device__ __forceinline__ void scene_closest(const SceneView &sc, v3 o, v3 d, float &best_t, int &best_id)
+{
+    for (int i = 0; i < sc.n_tris; i++) {
+        const float4 p1 = uniform_load(sc.tri_p1, i), e1 = uniform_load(sc.tri_e1, i), e2 = uniform_load(sc.tri_e2, i);
+        float t, det;
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
+    }
+    for (int i = 0; i < sc.n_sph; i++) {
+        const float4 s = uniform_load(sc.sph, i);
+        float t; bool front;
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
+    }
+}
+
+// HitInfo of the winner (rt.comp:144-147, 171-177): front face, normal, material.  det / front are recomputed with the
+// operations the test itself used, so they are the values the scan saw.
+__device__ __forceinline__ void finish_hit(const SceneView &sc, v3 o, v3 d, Hit &h)
+{
+    if (h.id < 0) return;
+    if (h.id >= sc.n_mesh + sc.n_tris) {
+        const int i = h.id - sc.n_mesh - sc.n_tris;
+        const float4 s = sc.sph[i];
+        float t; bool front;
+        hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        v3 point = o + d * h.t;                                         // rt.comp:144
+        v3 n = normalize(point - V(s.x, s.y, s.z));
+        h.front = front;
+        h.normal = front ? n : -n;                                      // rt.comp:147
+        h.mat = sc.sph_mat[i];
+    } else {
+        float4 p1, e1, e2, nr;
+        if (h.id >= sc.n_mesh) {
+            const int i = h.id - sc.n_mesh;
+            p1 = sc.tri_p1[i]; e1 = sc.tri_e1[i]; e2 = sc.tri_e2[i]; nr = sc.tri_nrm[i];
+        } else {
+            p1 = sc.mesh_p1[h.id]; e1 = sc.mesh_e1[h.id]; e2 = sc.mesh_e2[h.id]; nr = sc.mesh_nrm[h.id];
+        }
+        float t, det;
+        hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        v3 n = V(nr.x, nr.y, nr.z);
+        h.front = !(det < 0.0f);                                        // rt.comp:174
+        h.normal = det < 0.0f ? n : -n;                                 // rt.comp:177
+        h.mat = __float_as_uint(p1.w);
+    }
+}
+
 // CalculateRay (rt.comp:204-232) for the pixel of this lane; `alive` lanes take part, the mesh part is
 // wave-cooperative.  Canonical ids: mesh i | n_mesh + i | n_mesh + n_tris + i | -1.
 template <int SLOTS, class Store>
 __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int lane, bool alive, bool primary, v3 o, v3 d,
                                              unsigned &n_seg, unsigned &n_mesh_seg, unsigned &n_prim_mesh_seg,
-                                             unsigned &n_bvh_nodes, unsigned &n_bvh_tests)
+                                             unsigned &n_bvh_nodes, unsigned &n_bvh_tests, unsigned long long &cyc_mesh)
 {
     Hit h;
     h.id = -1; h.t = kInfinity; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
@@ -337,52 +436,17 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int
     n_mesh_seg += __popcll(gate_mask);
     n_prim_mesh_seg += __popcll(__ballot(gate && primary));
     if constexpr (Store::is_bvh) {
+        PT_TICK(b0);
         bvh_closest(sc, st, gate, o, d, h.t, h.id, n_bvh_nodes, n_bvh_tests);
+        PT_TICK(b1);
+        PT_ACC(cyc_mesh, b0, b1);
     } else {
         if (gate_mask) mesh_closest<SLOTS>(sc, st, lane, gate_mask, o, d, h.t, h.id);
     }
     if (!alive) return h;
 
-    float win_det = 0.0f;
-    int win_tri = -1;   // scene-triangle index of the current winner, if it is one
-    for (int i = 0; i < sc.n_tris; i++) {
-        const float4 p1 = uniform_load(sc.tri_p1, i), e1 = uniform_load(sc.tri_e1, i), e2 = uniform_load(sc.tri_e2, i);
-        float t, det;
-        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
-        if (has && t < h.t) { h.t = t; h.id = sc.n_mesh + i; win_tri = i; win_det = det; }
-    }
-    bool sph_front = false;
-    int win_sph = -1;
-    for (int i = 0; i < sc.n_sph; i++) {
-        const float4 s = uniform_load(sc.sph, i);
-        float t; bool front;
-        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
-        if (has && t < h.t) { h.t = t; h.id = sc.n_mesh + sc.n_tris + i; win_sph = i; sph_front = front; }
-    }
-    if (h.id < 0) return h;
-    if (win_sph >= 0) {
-        float4 s = sc.sph[win_sph];
-        v3 point = o + d * h.t;                                         // rt.comp:144
-        v3 n = normalize(point - V(s.x, s.y, s.z));
-        h.front = sph_front;
-        h.normal = sph_front ? n : -n;                                  // rt.comp:147
-        h.mat = sc.sph_mat[win_sph];
-    } else {
-        float4 p1, nr;
-        if (win_tri >= 0) {
-            p1 = sc.tri_p1[win_tri]; nr = sc.tri_nrm[win_tri];
-        } else {
-            // mesh winner: recompute det with the same operations the test used
-            p1 = sc.mesh_p1[h.id]; nr = sc.mesh_nrm[h.id];
-            float4 e1 = sc.mesh_e1[h.id], e2 = sc.mesh_e2[h.id];
-            float t;
-            hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, win_det);
-        }
-        v3 n = V(nr.x, nr.y, nr.z);
-        h.front = !(win_det < 0.0f);                                    // rt.comp:174
-        h.normal = win_det < 0.0f ? n : -n;                             // rt.comp:177
-        h.mat = __float_as_uint(p1.w);
-    }
+    scene_closest(sc, o, d, h.t, h.id);
+    finish_hit(sc, o, d, h);
     return h;
 }
 
@@ -451,6 +515,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
     const size_t plane = (size_t)fp.width * fp.height;
     unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
     unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
+    unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
     const unsigned long long t_start = wall_clock64();
     const int count0 = fp.class_count[0], count1 = fp.class_count[1], count2 = fp.class_count[2];
     const int per_tile0 = (fp.n_passes + fp.class_ppi[0] - 1) / fp.class_ppi[0], per_tile1 = (fp.n_passes + fp.class_ppi[1] - 1) / fp.class_ppi[1],
@@ -484,13 +549,16 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
             const bool alive = valid && k < k_end;
             if (!__any(alive)) break;
             n_iter++;
+            PT_TICK(c0);
             if (alive && fresh) {
                 ps.rng = primary_ray(fp, x, y, fp.first_pass + k, ps.o, ps.d);
                 ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
                 fresh = false;
             }
             n_samples += __popcll(__ballot(alive && ps.bounces == 0));
-            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.bounces == 0, ps.o, ps.d, n_seg, n_mesh_seg, n_prim_mesh_seg, n_bvh_nodes, n_bvh_tests);
+            PT_TICK(c1);
+            Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.bounces == 0, ps.o, ps.d, n_seg, n_mesh_seg, n_prim_mesh_seg, n_bvh_nodes, n_bvh_tests, cyc_mesh);
+            PT_TICK(c2);
             const bool hit = h.id >= 0 && h.t < kInfinity;
             n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
             if (alive) {
@@ -517,6 +585,8 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
                     fresh = true;
                 }
             }
+            PT_TICK(c3);
+            PT_ACC(cyc_gen, c0, c1); PT_ACC(cyc_trace, c1, c2); PT_ACC(cyc_shade, c2, c3);
         }
     }
     if constexpr (Store::is_bvh) {
@@ -533,6 +603,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
         atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
         atomicAdd(&fp.counters[6], (unsigned long long)n_prim_mesh_seg);
+        if (PT_PHASE_TIMERS) { atomicAdd(&fp.counters[12], cyc_gen); atomicAdd(&fp.counters[13], cyc_trace); atomicAdd(&fp.counters[14], cyc_shade); atomicAdd(&fp.counters[15], cyc_mesh); }
         const unsigned long long span = wall_clock64() - t_start;
         atomicAdd(&fp.counters[7], 1ull);
         atomicAdd(&fp.counters[8], span);
@@ -635,6 +706,26 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhStore st;
     st.stack = stack + wave * (kBvhStack * kWave) + lane;
+    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris;
+    trace_items_body<SLOTS>(sc, fp, st, lane);
+}
+
+// The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
+// LDS = nodes (64 B each) | triangles (48 B each) | stacks (stack_entries x 4 B x 512 lanes).
+constexpr int kBvhLdsBlock = 512;
+template <int SLOTS>
+__global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
+{
+    extern __shared__ float4 bvh_lds[];
+    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes;
+    unsigned *stack = reinterpret_cast<unsigned *>(tris + 3 * sc.n_mesh);
+    for (int i = threadIdx.x; i < 4 * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
+    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    BvhLdsStore st;
+    st.stack = stack + wave * (stack_entries * kWave) + lane;
+    st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris;
     trace_items_body<SLOTS>(sc, fp, st, lane);
 }
 
@@ -672,7 +763,8 @@ __device__ __forceinline__ void primary_hits_body(const SceneView &sc, const Fra
     uint32_t state = 0;
     if (valid) state = primary_ray(fp, x, y, fp.first_pass, o, d);
     unsigned a = 0, b = 0, c = 0, e = 0, f = 0;
-    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, true, o, d, a, b, c, e, f);
+    unsigned long long g = 0;
+    Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, true, o, d, a, b, c, e, f, g);
     if (!valid) return;
     const size_t i = (size_t)y * fp.width + x;
     if (fp.out_ids) fp.out_ids[i] = h.id;
@@ -695,6 +787,7 @@ __global__ void __launch_bounds__(kWave) pt_primary_hits_bvh(SceneView sc, Frame
     __shared__ unsigned stack[kBvhStack * kWave];
     BvhStore st;
     st.stack = stack + threadIdx.x;
+    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris;
     primary_hits_body<SLOTS>(sc, fp, st, threadIdx.x, blockIdx.x);
 }
 

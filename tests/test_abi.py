@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.pt_version() >= 1 and L.pt_kernel_name().decode() == "pt_trace_items_lds"
+    assert L.pt_version() >= 1 and L.pt_kernel_name().decode().startswith("pt_trace_items")
 
 
 def test_product_never_imports_the_oracle():

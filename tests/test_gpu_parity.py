@@ -235,7 +235,7 @@ def test_error_behaviour(capi, cameras, scenes):
     L.pt_destroy(h)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
 def test_kernel_variants_are_bit_identical(capi, variant, meta, cameras, scenes):
     """VGPR-resident and LDS-resident brute force and the BVH traversal must give the reference image (config 1 CRC) alike"""
     r = make(capi, scenes["default"], cameras["bench"], 640, 360, 4)
