@@ -221,6 +221,9 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         // passes per item (their items are short, and every item costs one ~11 ns device-wide atomic on the queue)
         static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 16;
         fp.class_ppi[0] = fp.chunk; fp.class_ppi[1] = std::max(1, std::min(np, mul1 * fp.chunk)); fp.class_ppi[2] = std::max(1, std::min(np, mul2 * fp.chunk));
+        static const int park_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 40, park_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 2;
+        static const int refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 8;
+        fp.park_high = park_high; fp.park_wait = park_wait; fp.refill_min = refill_min;
         fp.weights = (unsigned *)c->tile_weights.p; fp.order = (const unsigned *)c->tile_order.p; fp.class_count = (const int *)c->class_count.p;
         if (c->order_dirty) {
             hipLaunchKernelGGL(pt_tile_weights, dim3((unsigned)n_tiles), dim3(kWave), 0, c->stream, sv, fp);

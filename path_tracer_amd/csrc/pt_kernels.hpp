@@ -69,6 +69,8 @@ struct FrameParams {
     const int *class_count;   // [3] tiles per class: 0 = some pixel passes the mesh gate, 1 = hits only scene primitives, 2 = sky
     int class_ppi[3];         // passes per work item for each class
     unsigned *weights;        // per-tile sort key, written by pt_tile_weights
+    int park_high, park_wait; // BVH body: traverse when this many lanes are parked, or after this many iterations of waiting
+    int refill_min;           // BVH body: hand out new pixels once this many lanes are idle
     int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
                                     // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span [10] BVH node visits [11] BVH triangle tests
@@ -114,10 +116,16 @@ __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_fl
 #ifndef PT_PHASE_TIMERS
 #define PT_PHASE_TIMERS 0
 #endif
-#if PT_PHASE_TIMERS
+#if PT_PHASE_TIMERS == 1
 #define PT_TICK(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define PT_ACC(acc, a, b) acc += (b) - (a)
+#define PT_COUNT(acc, n)
+#elif PT_PHASE_TIMERS == 2     // event counts instead of cycles: [0] traversal phases [1] node steps [2] triangle steps [3] rays at phase entry
+#define PT_TICK(var)
+#define PT_ACC(acc, a, b)
+#define PT_COUNT(acc, n) acc += (n)
 #else
+#define PT_COUNT(acc, n)
 #define PT_TICK(var)
 #define PT_ACC(acc, a, b)
 #endif
@@ -611,6 +619,316 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// BVH body: the same persistent waves, work items and persistent lanes as trace_items_body, but a lane's path is a
+// small state machine so that rays which need the mesh can WAIT for each other:
+//   FRESH -> (primary ray) -> TRACE -> (root-AABB gate + scene primitives) -> READY, or MESH if the gate passed
+//   MESH  -> (BVH traversal, resumable)                                       -> READY
+//   READY -> (hit record, shading / sky, store)                               -> TRACE (next bounce) | FRESH (next pass) | DEAD
+// Every loop iteration runs the resolve / generate / trace phases for the lanes that are in those states.  The
+// traversal phase runs only when enough lanes are parked in MESH (fp.park_high), when they have waited fp.park_wait
+// iterations, or when nothing else is left to do; inside it every step is either one node visit or one triangle test for
+// the lanes that want that kind (majority vote), and it returns early once three quarters of its rays are finished,
+// leaving the rest parked WITH their traversal state (node, stack, best hit) to be resumed beside the next batch.  So the
+// traversal runs with most lanes busy instead of at the occupancy of whichever iteration a ray happened to be born in.
+// Scheduling only: a sample is a pure function of (pixel, pass); mesh-before-scene tie order is kept by the merge rule
+// in `finish`: a scene primitive wins only with a strictly smaller t (rt.comp:213-230 scans the mesh first).
+enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DIR = 5 };
+
+template <class Store>
+__device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
+{
+    const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
+    const size_t plane = (size_t)fp.width * fp.height;
+    unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
+    unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
+    unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
+    const unsigned long long t_start = wall_clock64();
+    const int count0 = fp.class_count[0], count1 = fp.class_count[1], count2 = fp.class_count[2];
+    const int per_tile0 = (fp.n_passes + fp.class_ppi[0] - 1) / fp.class_ppi[0], per_tile1 = (fp.n_passes + fp.class_ppi[1] - 1) / fp.class_ppi[1],
+              per_tile2 = (fp.n_passes + fp.class_ppi[2] - 1) / fp.class_ppi[2];
+    const int items0 = count0 * per_tile0, items1 = count1 * per_tile1;
+    const int n_items = items0 + items1 + count2 * per_tile2;
+    unsigned *stk = st.stack;
+    // Lanes are scheduled one by one: a lane that has finished its pixel takes the next unassigned pixel of the wave's
+    // current work item (64 px of a row x a range of passes), and the wave fetches another item from the queue when that
+    // one is used up.  So a wave keeps ~64 live paths whatever their lengths, and lanes parked for the mesh can wait for
+    // company without idling the others.
+    int t_valid = 0, t_next = 0, t_x0 = 0, t_y = 0, t_k0 = 0, t_kend = 0;   // wave-uniform cursor into the current item
+    bool more = true;                                                       // the queue may still hold items
+    int x = 0, y = 0, k = 0, k_end = 0;                                     // this lane's pixel and pass range
+    uint32_t pix_seed = 0;                                                  // pixelIndex (rt.comp:16); the rng seed is pass * pixelIndex
+    float pix_x = 0.0f, pix_y = 0.0f;                                       // pixelPos (rt.comp:14,17)
+    // a continuing path between the resolve and direction phases: hit point, normal, refraction index, mix weights
+    v3 hp = V(0, 0, 0), nrm = V(0, 0, 0);
+    float eta = 1.0f, mix_a = 0.0f, mix_b = 0.0f;
+    bool refr = false;
+    int state = S_DEAD;
+    PathState ps;
+    ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
+    // closest hit: scene primitives (s_t, s_id); mesh traversal / final result (best_t, best_id)
+    float s_t = kInfinity, best_t = kInfinity;
+    int s_id = -1, best_id = -1;
+    // resumable traversal state: cur >= 0 inner node to visit, cur < 0 inside a leaf at tri_pos .. tri_end
+    int cur = 0, sp = 0, tri_pos = 0, tri_end = 0;
+    v3 inv = V(0, 0, 0);
+    float delta = 0.0f;
+    int wait = 0;
+    {
+        for (;;) {
+            // ---- refill dead lanes with the next pixels
+            unsigned long long dead = __ballot(state == S_DEAD);
+            if (more && dead && (__popcll(dead) >= fp.refill_min || !__any(state == S_FRESH || state == S_TRACE || state == S_READY))) {
+                while (dead) {
+                    if (t_next >= t_valid) {
+                        // every wave stops fetching once the queue is drained
+                        unsigned fetched = 0;
+                        if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
+                        const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
+                        if (item >= n_items) { more = false; break; }
+                        // item -> (class, tile rank, pass chunk): classes are contiguous in rank and in item index
+                        int rel = item, rank0 = 0, cls = 0;
+                        if (rel >= items0) { rel -= items0; rank0 = count0; cls = 1; if (rel >= items1) { rel -= items1; rank0 += count1; cls = 2; } }
+                        const int per_tile = cls == 0 ? per_tile0 : cls == 1 ? per_tile1 : per_tile2;
+                        const int ppi = fp.class_ppi[cls];
+                        const int chunk = rel % per_tile;
+                        const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
+                        t_x0 = (tile % fp.x_blocks) * kWave; t_y = tile / fp.x_blocks;
+                        t_k0 = chunk * ppi; t_kend = min(fp.n_passes, (chunk + 1) * ppi);
+                        t_valid = min(kWave, fp.traced_width - t_x0); t_next = 0;
+                    }
+                    const int n_dead = __popcll(dead), room = t_valid - t_next;
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dead, 0));   // dead lanes below this one
+                    if (state == S_DEAD && rank < room) {
+                        x = t_x0 + t_next + rank; y = t_y; k = t_k0; k_end = t_kend;
+                        const float W = (float)fp.width, H = (float)fp.height;
+                        pix_seed = pixel_index(x, y, W, H);
+                        pix_x = ((((float)x / W) - 0.5f) * W) / H;      // rt.comp:14,17
+                        pix_y = ((float)y / H) - 0.5f;
+                        state = S_FRESH;
+                    }
+                    t_next += min(n_dead, room);
+                    dead = __ballot(state == S_DEAD);
+                }
+            }
+            const unsigned long long m_mesh = __ballot(state == S_MESH);
+            const unsigned long long m_other = __ballot(state == S_FRESH || state == S_TRACE || state == S_READY);   // S_DIR never survives an iteration
+            if (!(m_mesh | m_other)) break;      // nothing alive and (refill ran) nothing left in the queue
+            n_iter++;
+            const int n_mesh = __popcll(m_mesh), n_other = __popcll(m_other);
+            PT_TICK(c0);
+            if (n_mesh && (n_mesh >= fp.park_high || n_other == 0 || wait >= fp.park_wait)) {
+                // ---- traversal phase
+                wait = 0;
+                PT_COUNT(cyc_gen, 1); PT_COUNT(cyc_mesh, n_mesh);
+                const int exit_at = n_other > 0 ? n_mesh / 4 : 0;
+                const v3 olo = V(ps.o.x + delta, ps.o.y + delta, ps.o.z + delta), ohi = V(ps.o.x - delta, ps.o.y - delta, ps.o.z - delta);
+                for (;;) {
+                    const int n = __popcll(__ballot(state == S_MESH));
+                    if (n <= exit_at) break;
+                    const int n_node = __popcll(__ballot(state == S_MESH && cur >= 0));
+                    int next = 0;
+                    bool moved = false, fin = false;       // lane got a new node/leaf code in `next`, or finished its ray
+                    if (2 * n_node >= n) {
+                        PT_COUNT(cyc_trace, 1);
+                        if (state == S_MESH && cur >= 0) {
+                            float4 a, b, c;
+                            int kl, kr;
+                            st.node(cur, a, b, c, kl, kr);
+                            n_bvh_nodes++;
+                            float l0, l1, r0, r1;
+                            slab_test(a.x, a.y, a.z, a.w, b.x, b.y, olo, ohi, inv, l0, l1);
+                            slab_test(b.z, b.w, c.x, c.y, c.z, c.w, olo, ohi, inv, r0, r1);
+                            const float lim = fmaf(best_t, 1.001f, delta);
+                            const bool hl = l0 <= l1 && l0 <= lim, hr = r0 <= r1 && r0 <= lim;
+                            moved = true;
+                            if (hl && hr) {
+                                const bool left_first = l0 <= r0;
+                                next = left_first ? kl : kr;
+                                stk[sp * kWave] = (unsigned)(left_first ? kr : kl);
+                                sp++;
+                            } else if (hl) {
+                                next = kl;
+                            } else if (hr) {
+                                next = kr;
+                            } else if (sp == 0) {
+                                fin = true;
+                            } else {
+                                sp--;
+                                next = (int)stk[sp * kWave];
+                            }
+                        }
+                    } else {
+                        PT_COUNT(cyc_shade, 1);
+                        if (state == S_MESH && cur < 0) {
+                            float4 p1, e1, e2;
+                            st.tri(tri_pos, p1, e1, e2);
+                            float t, det;
+                            bool bad = false;
+                            bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad);
+                            if (__builtin_expect(bad, 0)) has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
+                            const int id = __float_as_int(p1.w);
+                            n_bvh_tests++;
+                            if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+                            tri_pos++;
+                            if (tri_pos == tri_end) {
+                                moved = true;
+                                if (sp == 0) fin = true;
+                                else { sp--; next = (int)stk[sp * kWave]; }
+                            }
+                        }
+                    }
+                    if (moved) {
+                        if (fin) {
+                            // merge with the scene primitives: they come later in the reference's scan, so they need a strictly smaller t
+                            if (s_id >= 0 && s_t < best_t) { best_t = s_t; best_id = s_id; }
+                            state = S_READY;
+                        } else if (next >= 0) {
+                            cur = next;
+                        } else {
+                            const int code = ~next;
+                            tri_pos = code >> 3; tri_end = tri_pos + (code & 7) + 1;
+                            cur = -1;
+                        }
+                    }
+                }
+            } else if (n_mesh) {
+                wait++;
+            }
+            PT_TICK(c1);
+            PT_ACC(cyc_mesh, c0, c1);
+            // ---- resolve phase (rt.comp:273-322), up to the point where a continuing path needs its random direction
+            if (__any(state == S_READY)) {
+                n_hits += __popcll(__ballot(state == S_READY && best_id >= 0 && best_t < kInfinity && !fp.debug_normal));
+                if (state == S_READY) {
+                    Hit h;
+                    h.id = best_id; h.t = best_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
+                    finish_hit(sc, ps.o, ps.d, h);
+                    const bool hit = h.id >= 0 && h.t < kInfinity;
+                    bool done = true;
+                    v3 colour;
+                    if (hit && fp.debug_normal) {
+                        colour = h.normal;                              // rt.comp:274
+                    } else {
+                        if (hit) {
+                            // rt.comp:276-311; the draws keep the shader's order: specular, refraction, then the direction
+                            ps.bounces++;
+                            const PtMaterial *m = &sc.mats[h.mat];
+                            const float m_ior = m->ior, m_smooth = m->smoothness;
+                            const float ior = h.front ? (1.0f / m_ior) : m_ior;
+                            const bool is_spec = m->specularChance > random_value(ps.rng);
+                            const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);
+                            const bool is_refr = fres < random_value(ps.rng);
+                            const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
+                            const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
+                            ps.emitted = ps.emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
+                            ps.ray_color = ps.ray_color * select3(is_refr, base, select3(is_spec, spec, base));
+                            ps.incoming = ps.incoming + ps.emitted * ps.ray_color;
+                            done = ps.bounces >= max_bounces;
+                            if (!done) {
+                                // the new direction (rt.comp:296-305) is finished in the direction phase; at the last
+                                // bounce the shader computes one too, but nothing reads it
+                                hp = ps.o + ps.d * h.t;                 // hitPoint (rt.comp:175 / :144)
+                                nrm = h.normal; eta = ior; refr = is_refr;
+                                mix_a = is_spec ? m->specularSmoothness : m_smooth; mix_b = m_smooth;
+                                state = S_DIR;
+                            }
+                        } else {
+                            ps.bounces++;
+                            ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);  // skyColor * skyIntensity (rt.comp:315)
+                            ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
+                        }
+                        const float nb = (float)ps.bounces;
+                        colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
+                    }
+                    if (done) {
+                        fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                        k++;
+                        state = k < k_end ? S_FRESH : S_DEAD;
+                    }
+                }
+            }
+            PT_TICK(c2);
+            PT_ACC(cyc_shade, c1, c2);
+            // ---- direction phase: RandomDirection (rt.comp:85-90) once for both of its callers -- the jitter of a new
+            // primary ray (rt.comp:326-333) and the bounce direction of a continuing path (rt.comp:296-305)
+            if (__any(state == S_FRESH || state == S_DIR)) {
+                n_samples += __popcll(__ballot(state == S_FRESH));
+                if (state == S_FRESH || state == S_DIR) {
+                    const bool fresh = state == S_FRESH;
+                    if (fresh) ps.rng = (uint32_t)(fp.first_pass + k) * pix_seed;       // rt.comp:327
+                    const float gx = random_value_nd(ps.rng), gy = random_value_nd(ps.rng), gz = random_value_nd(ps.rng);
+                    const v3 g = V(gx, gy, gz);
+                    const float gr = 1.0f / sqrtf(dot(g, g));           // normalize(v) = v * (1/sqrt(dot(v,v)))
+                    if (fresh) {
+                        // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
+                        const v3 jit = (g * 0.00025f) * gr;
+                        const float X = -pix_x + jit.x, Y = pix_y + jit.y;
+                        const float *m = fp.iv;
+                        ps.d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
+                        ps.o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
+                        ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
+                    } else {
+                        const v3 r = g * gr;
+                        const v3 hemi = dot(r, nrm) > 0.0f ? r : -r;    // rt.comp:92-95
+                        const v3 a = mix3(hemi, reflect3(ps.d, nrm), mix_a);
+                        const v3 b = mix3(-hemi, refract3(ps.d, nrm, eta), mix_b);
+                        ps.d = normalize(select3(refr, b, a));
+                        ps.o = hp + ps.d * 0.0002f;                     // rt.comp:305
+                    }
+                    state = S_TRACE;
+                }
+            }
+            PT_TICK(c3);
+            PT_ACC(cyc_gen, c2, c3);
+            // ---- trace phase: root-AABB gate (rt.comp:213) and scene primitives (rt.comp:219-230); the mesh is deferred
+            if (__any(state == S_TRACE)) {
+                bool gate = false;
+                if (state == S_TRACE) {
+                    if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
+                    s_t = kInfinity; s_id = -1;
+                    scene_closest(sc, ps.o, ps.d, s_t, s_id);
+                }
+                n_seg += __popcll(__ballot(state == S_TRACE));
+                n_mesh_seg += __popcll(__ballot(gate));
+                n_prim_mesh_seg += __popcll(__ballot(gate && ps.bounces == 0));
+                if (state == S_TRACE) {
+                    if (gate) {
+                        state = S_MESH;
+                        cur = 0; sp = 0; best_t = kInfinity; best_id = -1;
+                        inv = V(1.0f / ps.d.x, 1.0f / ps.d.y, 1.0f / ps.d.z);
+                        delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
+                    } else {
+                        state = S_READY;
+                        best_t = s_t; best_id = s_id;
+                    }
+                }
+            }
+            PT_TICK(c4);
+            PT_ACC(cyc_trace, c3, c4);
+        }
+    }
+    if (fp.counters) {
+        for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); }
+        if (lane == 0) {
+            atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
+            atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
+            atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
+            atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
+            atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
+            atomicAdd(&fp.counters[6], (unsigned long long)n_prim_mesh_seg);
+            atomicAdd(&fp.counters[10], (unsigned long long)n_bvh_nodes);
+            atomicAdd(&fp.counters[11], (unsigned long long)n_bvh_tests);
+            if (PT_PHASE_TIMERS) { atomicAdd(&fp.counters[12], cyc_gen); atomicAdd(&fp.counters[13], cyc_trace); atomicAdd(&fp.counters[14], cyc_shade); atomicAdd(&fp.counters[15], cyc_mesh); }
+            const unsigned long long span = wall_clock64() - t_start;
+            atomicAdd(&fp.counters[7], 1ull);
+            atomicAdd(&fp.counters[8], span);
+            atomicMax(&fp.counters[9], span);
+        }
+    }
+}
+
 // VGPR-resident triangles: persistent single-wave workgroups, 3 waves/SIMD (any mesh size).
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
@@ -707,7 +1025,7 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
     BvhStore st;
     st.stack = stack + wave * (kBvhStack * kWave) + lane;
     st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris;
-    trace_items_body<SLOTS>(sc, fp, st, lane);
+    trace_items_body_bvh(sc, fp, st, lane);
 }
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
@@ -726,7 +1044,7 @@ __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneV
     BvhLdsStore st;
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris;
-    trace_items_body<SLOTS>(sc, fp, st, lane);
+    trace_items_body_bvh(sc, fp, st, lane);
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
