@@ -55,7 +55,7 @@ struct pt_ctx {
     int n_timed = 0;
     DevBuf radiance;                   // [batch passes][H][W] float4 workspace
     size_t workspace_limit = (size_t)4 << 30;
-    int chunk_passes = 2;              // passes per work item
+    int chunk_passes = 4;              // passes per work item (mesh tiles; others take multiples)
     DevBuf queue;                      // work-item counter of pt_trace_items
     DevBuf tile_weights, tile_order, class_count;   // schedule of pt_trace_items: tiles sorted heaviest first
     bool order_dirty = true;           // camera, scene, size or stream changed since the schedule was made

@@ -317,6 +317,18 @@ __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float
     t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2)) * 1.000001f;
 }
 
+// The same test with the origin folded in: t = b * inv + (-(o +- delta) * inv), one FMA per plane, three-input min/max.
+// A ray that starts inside the grown box has t0 < 0 <= t1.  (inf - inf = NaN for an axis-parallel ray drops out as above.)
+__device__ __forceinline__ void slab_test_fma(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 nlo, v3 nhi, v3 inv,
+                                              float &t0, float &t1)
+{
+    const float x1 = fmaf(mnx, inv.x, nlo.x), x2 = fmaf(mxx, inv.x, nhi.x);
+    const float y1 = fmaf(mny, inv.y, nlo.y), y2 = fmaf(mxy, inv.y, nhi.y);
+    const float z1 = fmaf(mnz, inv.z, nlo.z), z2 = fmaf(mxz, inv.z, nhi.z);
+    t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2)), __builtin_fminf(z1, z2));
+    t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2)), __builtin_fmaxf(z1, z2)) * 1.000001f;
+}
+
 template <class Store>
 __device__ __forceinline__ void bvh_closest(const SceneView &sc, Store &st, bool gate, v3 o, v3 d, float &best_t, int &best_id,
                                             unsigned &n_nodes, unsigned &n_tests)
@@ -723,7 +735,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 wait = 0;
                 PT_COUNT(cyc_gen, 1); PT_COUNT(cyc_mesh, n_mesh);
                 const int exit_at = n_other > 0 ? n_mesh / 4 : 0;
-                const v3 olo = V(ps.o.x + delta, ps.o.y + delta, ps.o.z + delta), ohi = V(ps.o.x - delta, ps.o.y - delta, ps.o.z - delta);
+                const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
+                const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
                 for (;;) {
                     const int n = __popcll(__ballot(state == S_MESH));
                     if (n <= exit_at) break;
@@ -738,10 +751,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             st.node(cur, a, b, c, kl, kr);
                             n_bvh_nodes++;
                             float l0, l1, r0, r1;
-                            slab_test(a.x, a.y, a.z, a.w, b.x, b.y, olo, ohi, inv, l0, l1);
-                            slab_test(b.z, b.w, c.x, c.y, c.z, c.w, olo, ohi, inv, r0, r1);
+                            slab_test_fma(a.x, a.y, a.z, a.w, b.x, b.y, nlo, nhi, inv, l0, l1);
+                            slab_test_fma(b.z, b.w, c.x, c.y, c.z, c.w, nlo, nhi, inv, r0, r1);
                             const float lim = fmaf(best_t, 1.001f, delta);
-                            const bool hl = l0 <= l1 && l0 <= lim, hr = r0 <= r1 && r0 <= lim;
+                            const bool hl = l0 <= l1 && l1 >= 0.0f && l0 <= lim, hr = r0 <= r1 && r1 >= 0.0f && r0 <= lim;
                             moved = true;
                             if (hl && hr) {
                                 const bool left_first = l0 <= r0;
@@ -762,16 +775,24 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     } else {
                         PT_COUNT(cyc_shade, 1);
                         if (state == S_MESH && cur < 0) {
-                            float4 p1, e1, e2;
+                            // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
+                            const bool two = tri_pos + 1 < tri_end;
+                            float4 p1, e1, e2, q1, f1, f2;
                             st.tri(tri_pos, p1, e1, e2);
-                            float t, det;
+                            st.tri(two ? tri_pos + 1 : tri_pos, q1, f1, f2);
+                            float t, det, t2, det2;
                             bool bad = false;
                             bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad);
-                            if (__builtin_expect(bad, 0)) has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
-                            const int id = __float_as_int(p1.w);
-                            n_bvh_tests++;
+                            bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad);
+                            if (__builtin_expect(bad, 0)) {
+                                has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
+                                has2 = hit_triangle(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2);
+                            }
+                            const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
+                            n_bvh_tests += two ? 2 : 1;
                             if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                            tri_pos++;
+                            if (two && has2 && (t2 < best_t || (t2 == best_t && id2 < best_id))) { best_t = t2; best_id = id2; }
+                            tri_pos += two ? 2 : 1;
                             if (tri_pos == tri_end) {
                                 moved = true;
                                 if (sp == 0) fin = true;
@@ -897,7 +918,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     if (gate) {
                         state = S_MESH;
                         cur = 0; sp = 0; best_t = kInfinity; best_id = -1;
-                        inv = V(1.0f / ps.d.x, 1.0f / ps.d.y, 1.0f / ps.d.z);
+                        // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
+                        inv = V(__builtin_amdgcn_rcpf(ps.d.x), __builtin_amdgcn_rcpf(ps.d.y), __builtin_amdgcn_rcpf(ps.d.z));
                         delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
                     } else {
                         state = S_READY;

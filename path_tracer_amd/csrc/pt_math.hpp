@@ -133,9 +133,10 @@ __device__ __forceinline__ uint32_t pixel_index(int x, int y, float W, float H)
 }
 
 // rt.comp:102-124
+__device__ __forceinline__ float exact_rcp(float x);
 __device__ __forceinline__ bool hit_aabb(v3 bmin, v3 bmax, v3 o, v3 d)
 {
-    float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    float ix = exact_rcp(d.x), iy = exact_rcp(d.y), iz = exact_rcp(d.z);      // == 1.0f / d.*, bit for bit
     float tx1 = (bmin.x - o.x) * ix, tx2 = (bmax.x - o.x) * ix;
     float tmin = minps(tx1, tx2), tmax = maxps(tx1, tx2);
     float ty1 = (bmin.y - o.y) * iy, ty2 = (bmax.y - o.y) * iy;
@@ -168,11 +169,12 @@ __device__ __forceinline__ float fast_rcp_checked(float x, bool &bad)
     bad = bad || !__builtin_amdgcn_classf(r, 0x108);             // not +-normal
     return r;
 }
-__device__ __forceinline__ float exact_rcp(float x)              // reference form for tools/rcp_exact.hip
+__device__ __forceinline__ float exact_rcp(float x)              // == 1.0f / x for every x (tools/rcp_exact.hip)
 {
     bool bad = false;
     float r = fast_rcp_checked(x, bad);
-    return bad ? 1.0f / x : r;
+    if (__builtin_expect(bad, 0)) r = 1.0f / x;
+    return r;
 }
 
 // rt.comp:153-173 with e1 = p2-p1, e2 = p3-p1 precomputed (one rounding each, identical to the
