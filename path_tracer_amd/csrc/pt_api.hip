@@ -69,8 +69,14 @@ struct pt_ctx {
     float *accum = nullptr;            // own or external
     bool accum_external = false;
 
-    DevBuf bvh_nodes, bvh_tris;        // BVH over the mesh (pt_bvh.hpp); bvh_ok = usable (finite coordinates, depth within the stack)
-    bool bvh_ok = false; float bvh_scale = 0.0f; int bvh_depth = 0, bvh_n_nodes = 0;
+    // BVHs (pt_bvh.hpp): one tree over the mesh triangles (built by pt_upload_mesh), one over the spheres (pt_upload_scene);
+    // their nodes are concatenated (mesh tree first, root 0) and uploaded by sync_bvh before the next launch
+    DevBuf bvh_nodes, bvh_tris, bvh_sph;
+    std::vector<BvhNode> h_mesh_nodes, h_sph_nodes;
+    bool mesh_bvh_ok = false, sph_bvh_ok = false, nodes_dirty = true;
+    float mesh_scale = 0.0f, sph_scale = 0.0f; int mesh_depth = 0, sph_depth = 0;
+    bool bvh_ok = false;               // the traversal variants can run (something to traverse, nothing the builder refused in the mesh)
+    float bvh_scale = 0.0f; int bvh_depth = 0, bvh_n_nodes = 0, sph_root = -1;
     DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, counters;
     int n_mesh = 0, n_chunks = 0, n_tris = 0, n_sph = 0, n_mats = 0;
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
@@ -144,6 +150,7 @@ SceneView scene_view(const pt_ctx *c)
     s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
     s.mats = (const PtMaterial *)c->mats.p;
     s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
+    s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root; s.n_sph_nodes = (int)c->h_sph_nodes.size();
     return s;
 }
 
@@ -169,7 +176,36 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
 constexpr size_t kBvhLdsLimit = 80 * 1024;
 size_t bvh_lds_bytes(const pt_ctx *c)
 {
-    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (size_t)(c->bvh_depth + 1) * 4 * kBvhLdsBlock;
+    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)(c->bvh_depth + 1) * 4 * kBvhLdsBlock;
+}
+
+// Concatenate the two trees' nodes (mesh first: its root is node 0; the sphere tree's child indices are shifted) and upload.
+int sync_bvh(pt_ctx *c)
+{
+    if (!c->nodes_dirty) return PT_OK;
+    const bool mesh = c->n_mesh > 0 && c->mesh_bvh_ok, sph = c->n_sph > 0 && c->sph_bvh_ok;
+    c->bvh_ok = (c->n_mesh == 0 || c->mesh_bvh_ok) && (mesh || sph);
+    c->sph_root = -1; c->bvh_n_nodes = 0; c->bvh_depth = 0; c->bvh_scale = 0.0f;
+    if (c->bvh_ok) {
+        std::vector<BvhNode> all;
+        if (mesh) all = c->h_mesh_nodes;
+        if (sph) {
+            const int base = (int)all.size();
+            c->sph_root = base;
+            for (BvhNode nd : c->h_sph_nodes) {
+                if (nd.left >= 0) nd.left += base;
+                if (nd.right >= 0) nd.right += base;
+                all.push_back(nd);
+            }
+        }
+        HIPCHK(c, c->bvh_nodes.upload(all.data(), all.size() * sizeof(BvhNode), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->bvh_n_nodes = (int)all.size();
+        c->bvh_depth = std::max(mesh ? c->mesh_depth : 0, sph ? c->sph_depth : 0) + 1;   // + the other tree's root on the stack
+        c->bvh_scale = std::max(mesh ? c->mesh_scale : 0.0f, sph ? c->sph_scale : 0.0f);
+    }
+    c->nodes_dirty = false;
+    return PT_OK;
 }
 
 // Kernel variant for the uploaded mesh.  Default: the BVH traversal whenever the builder accepted the mesh; brute
@@ -189,6 +225,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     if (rc) return rc;
     if (first_pass < 0 || n_passes < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, n_passes);
     Bind b(c); HIPCHK(c, b.e);
+    if ((rc = sync_bvh(c)) != PT_OK) return rc;
     const size_t plane_bytes = (size_t)c->width * c->height * sizeof(float4);
     const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, c->workspace_limit / plane_bytes));
     if (c->radiance.bytes < plane_bytes * batch) {
@@ -224,6 +261,8 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         static const int park_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 40, park_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 2;
         static const int refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 8;
         fp.park_high = park_high; fp.park_wait = park_wait; fp.refill_min = refill_min;
+        static const int park_exit = getenv("PT_PARK_EXIT") ? atoi(getenv("PT_PARK_EXIT")) : 2;
+        fp.park_exit = park_exit;
         fp.weights = (unsigned *)c->tile_weights.p; fp.order = (const unsigned *)c->tile_order.p; fp.class_count = (const int *)c->class_count.p;
         if (c->order_dirty) {
             hipLaunchKernelGGL(pt_tile_weights, dim3((unsigned)n_tiles), dim3(kWave), 0, c->stream, sv, fp);
@@ -247,11 +286,17 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         } else if (variant == 6) {
             const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
             const size_t lds = bvh_lds_bytes(c);
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_bvh_lds<kSlots>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(pt_trace_items_bvh_lds<kSlots>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
+            if (c->sph_root >= 0) {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_bvh_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(pt_trace_items_bvh_lds<true>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
+            } else {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_bvh_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(pt_trace_items_bvh_lds<false>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
+            }
         } else if (variant == 5) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 4);
-            hipLaunchKernelGGL(pt_trace_items_bvh<kSlots>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+            if (c->sph_root >= 0) hipLaunchKernelGGL(pt_trace_items_bvh<true>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+            else hipLaunchKernelGGL(pt_trace_items_bvh<false>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
         } else {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
@@ -309,7 +354,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
@@ -398,7 +443,7 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
             const float v[3] = {tris[i].p1[k], tris[i].p2[k], tris[i].p3[k]};
             for (float x : v) { if (!std::isfinite(x)) finite = false; else scale = std::max(scale, std::fabs(x)); }
         }
-    c->bvh_ok = false;
+    c->mesh_bvh_ok = false; c->nodes_dirty = true;
     std::vector<float4> btris;
     if (n > 0 && finite && scale < 1e18f) {
         build_bvh(tris, n, bvh);
@@ -410,9 +455,9 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
                 btris[3 * (size_t)j] = make_float4(p1[i].x, p1[i].y, p1[i].z, idf);
                 btris[3 * (size_t)j + 1] = e1[i]; btris[3 * (size_t)j + 2] = e2[i];
             }
-            HIPCHK(c, c->bvh_nodes.upload(bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), c->stream));
             HIPCHK(c, c->bvh_tris.upload(btris.data(), btris.size() * sizeof(float4), c->stream));
-            c->bvh_ok = true; c->bvh_scale = scale; c->bvh_depth = bvh.depth; c->bvh_n_nodes = (int)bvh.nodes.size();
+            c->h_mesh_nodes.swap(bvh.nodes);
+            c->mesh_bvh_ok = true; c->mesh_scale = scale; c->mesh_depth = bvh.depth;
         }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));    // host staging vectors die here
@@ -445,6 +490,33 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     HIPCHK(c, c->sph.upload(sp.data(), sp.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->sph_mat.upload(sm.data(), sm.size() * sizeof(uint32_t), c->stream));
     HIPCHK(c, c->mats.upload(mats, (size_t)n_mats * sizeof(PtMaterial), c->stream));
+    // sphere tree for the traversal variants (records in leaf order: (centre, radius), (bits(index), 0, 0, 0))
+    c->sph_bvh_ok = false; c->nodes_dirty = true;
+    std::vector<float4> srec;
+    {
+        bool finite = true; float scale = 0.0f;
+        for (int i = 0; i < n_sph && finite; i++) {
+            const float v[4] = {sph[i].position[0], sph[i].position[1], sph[i].position[2], sph[i].radius};
+            for (float x : v) { if (!std::isfinite(x)) finite = false; }
+            for (int k = 0; k < 3; k++) scale = std::max(scale, std::fabs(sph[i].position[k]) + std::fabs(sph[i].radius));
+        }
+        if (n_sph > 0 && finite && scale < 1e18f) {
+            Bvh bvh;
+            build_sphere_bvh(sph, n_sph, bvh);
+            if (bvh.depth <= kBvhMaxDepth && (int)bvh.order.size() == n_sph) {
+                srec.resize((size_t)2 * n_sph);
+                for (int j = 0; j < n_sph; j++) {
+                    const int i = bvh.order[j];
+                    float idf; std::memcpy(&idf, &i, 4);
+                    srec[2 * (size_t)j] = sp[i];
+                    srec[2 * (size_t)j + 1] = make_float4(idf, 0.0f, 0.0f, 0.0f);
+                }
+                HIPCHK(c, c->bvh_sph.upload(srec.data(), srec.size() * sizeof(float4), c->stream));
+                c->h_sph_nodes.swap(bvh.nodes);
+                c->sph_bvh_ok = true; c->sph_scale = scale; c->sph_depth = bvh.depth;
+            }
+        }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_tris = n_tris; c->n_sph = n_sph; c->n_mats = n_mats; c->max_mat_scene = maxm;
     c->have_scene = true; c->order_dirty = true;
@@ -534,6 +606,7 @@ int pt_read_primary_hits(pt_ctx *c, int pass, int32_t *ids, float *t, float *dir
     int rc = check_ready(c);
     if (rc) return rc;
     Bind b(c); HIPCHK(c, b.e);
+    if ((rc = sync_bvh(c)) != PT_OK) return rc;
     const size_t n = (size_t)c->width * c->height;
     int32_t *d_ids = nullptr; float *d_t = nullptr, *d_dirs = nullptr; uint32_t *d_rng = nullptr;
     auto cleanup = [&]() { if (d_ids) (void)hipFree(d_ids); if (d_t) (void)hipFree(d_t); if (d_dirs) (void)hipFree(d_dirs); if (d_rng) (void)hipFree(d_rng); };

@@ -14,14 +14,12 @@
 #include <vector>
 
 #include "../../include/pt_hip.h"
+#include "pt_bvh_format.hpp"
 
 namespace pt {
 
-constexpr int kLeafMax = 4;          // triangles per leaf the builder aims for (the leaf code holds up to 8)
-constexpr int kBvhMaxDepth = 40;     // inner-node depth bound == per-lane traversal stack entries
-
 // 64-byte inner node: both child boxes + child codes.  code >= 0: inner node index; code < 0: leaf,
-// ~code = first_leaf_triangle << 3 | (count - 1).
+// ~code = flag | first_leaf_primitive << 3 | (count - 1), flag = kSphereLeaf for leaves of the sphere tree.
 struct BvhNode {
     float lmin[3], lmax[3], rmin[3], rmax[3];
     int32_t left, right, pad0, pad1;
@@ -53,6 +51,7 @@ struct Ref { Box b; float c[3]; int idx; };
 struct Builder {
     std::vector<Ref> refs;
     Bvh *out;
+    int leaf_flag = 0;
 
     static int ceil_log2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
@@ -62,7 +61,7 @@ struct Builder {
         std::sort(refs.begin() + lo, refs.begin() + hi, [](const Ref &a, const Ref &b) { return a.idx < b.idx; });
         const int first = (int)out->order.size();
         for (int i = lo; i < hi; i++) out->order.push_back(refs[i].idx);
-        return ~((first << 3) | (hi - lo - 1));
+        return ~(leaf_flag | (first << 3) | (hi - lo - 1));
     }
 
     Box bounds(int lo, int hi) const { Box b; b.reset(); for (int i = lo; i < hi; i++) b.grow(refs[i].b); return b; }
@@ -133,22 +132,18 @@ struct Builder {
 
 }  // namespace bvh_detail
 
-inline void build_bvh(const PtTriangle *tris, int n, Bvh &out)
+// Builds over refs already filled with boxes/centroids/indices.
+inline void build_from_refs(bvh_detail::Builder &b, Bvh &out)
 {
     using namespace bvh_detail;
+    const int n = (int)b.refs.size();
     out.nodes.clear(); out.order.clear(); out.depth = 0;
     if (n <= 0) return;
-    Builder b; b.out = &out; b.refs.resize(n);
+    b.out = &out;
     out.order.reserve(n);
     out.nodes.reserve(std::max(1, n / 2));
-    for (int i = 0; i < n; i++) {
-        Ref &r = b.refs[i];
-        r.b.reset(); r.b.grow(tris[i].p1); r.b.grow(tris[i].p2); r.b.grow(tris[i].p3);
-        for (int k = 0; k < 3; k++) r.c[k] = 0.5f * r.b.mn[k] + 0.5f * r.b.mx[k];
-        r.idx = i;
-    }
     if (n <= kLeafMax) {
-        // the traversal starts at an inner node: root = (leaf of everything, empty)
+        // the traversal starts at an inner node: root = (leaf of everything, the same leaf again)
         out.nodes.emplace_back();
         const Box lb = b.bounds(0, n);
         const int l = b.make_leaf(0, n);
@@ -160,6 +155,33 @@ inline void build_bvh(const PtTriangle *tris, int n, Bvh &out)
         return;
     }
     b.build(0, n, 0);
+}
+
+inline void build_bvh(const PtTriangle *tris, int n, Bvh &out)
+{
+    using namespace bvh_detail;
+    Builder b; b.refs.resize(std::max(0, n));
+    for (int i = 0; i < n; i++) {
+        Ref &r = b.refs[i];
+        r.b.reset(); r.b.grow(tris[i].p1); r.b.grow(tris[i].p2); r.b.grow(tris[i].p3);
+        for (int k = 0; k < 3; k++) r.c[k] = 0.5f * r.b.mn[k] + 0.5f * r.b.mx[k];
+        r.idx = i;
+    }
+    build_from_refs(b, out);
+}
+
+// The spheres of the scene (SSBO 4): boxes centre -+ radius (the traversal's per-ray margin covers the rounding).
+inline void build_sphere_bvh(const PtSphere *sph, int n, Bvh &out)
+{
+    using namespace bvh_detail;
+    Builder b; b.refs.resize(std::max(0, n)); b.leaf_flag = kSphereLeaf;
+    for (int i = 0; i < n; i++) {
+        Ref &r = b.refs[i];
+        const float rad = std::fabs(sph[i].radius);
+        for (int k = 0; k < 3; k++) { r.b.mn[k] = sph[i].position[k] - rad; r.b.mx[k] = sph[i].position[k] + rad; r.c[k] = sph[i].position[k]; }
+        r.idx = i;
+    }
+    build_from_refs(b, out);
 }
 
 }  // namespace pt

@@ -14,6 +14,7 @@
 // "lowest index".
 #pragma once
 #include "pt_math.hpp"
+#include "pt_bvh_format.hpp"
 #include "../../include/pt_hip.h"
 
 #pragma clang fp contract(off)
@@ -29,7 +30,7 @@ namespace pt {
 constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
 constexpr int kNumCounters = 16;
-constexpr int kBvhStack = 40;                // == kBvhMaxDepth (pt_bvh.hpp): per-lane traversal stack entries
+constexpr int kBvhStack = kBvhMaxDepth + 1;   // per-lane traversal stack entries (one extra: the sphere tree's root under the mesh tree)
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
 struct SceneView {
@@ -49,7 +50,10 @@ struct SceneView {
     // BVH over the mesh triangles (pt_bvh.hpp), used by the traversal variant
     const float4 *bvh_nodes;  // 4 x float4 per inner node: both child boxes + child codes
     const float4 *bvh_tris;   // 3 x float4 per triangle in leaf order: (p1, bits(original index)), e1, e2
-    float bvh_scale;          // largest |coordinate| of the mesh (for the traversal's safety margin)
+    float bvh_scale;          // largest |coordinate| of the mesh and the spheres (for the traversal's safety margin)
+    const float4 *bvh_sph;    // sphere tree leaves, 2 x float4 per sphere in leaf order: (centre, radius), (bits(sphere index), -, -, -)
+    int sph_root;             // node index of the sphere tree's root in bvh_nodes, -1: spheres are scanned one by one
+    int n_sph_nodes;
 };
 
 struct FrameParams {
@@ -71,6 +75,7 @@ struct FrameParams {
     unsigned *weights;        // per-tile sort key, written by pt_tile_weights
     int park_high, park_wait; // BVH body: traverse when this many lanes are parked, or after this many iterations of waiting
     int refill_min;           // BVH body: hand out new pixels once this many lanes are idle
+    int park_exit;            // BVH body: leave the traversal phase when park_exit/8 of its rays are still unfinished
     int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
                                     // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span [10] BVH node visits [11] BVH triangle tests
@@ -282,6 +287,8 @@ struct BvhStore {
         const float4 *t = tris + 3 * (size_t)j;
         p1 = t[0]; e1 = t[1]; e2 = t[2];
     }
+    const float4 *sph;
+    __device__ __forceinline__ void sphere(int j, float4 &cr, int &index) const { cr = sph[2 * j]; index = __float_as_int(sph[2 * j + 1].x); }
 };
 // ... or copied into the workgroup's LDS (meshes whose nodes + triangles fit beside the stacks): a dependent node
 // fetch then costs ~100 cycles instead of an L2 round trip, and the traversal is a chain of them.
@@ -303,6 +310,8 @@ struct BvhLdsStore {
         lds_cf4v *t = tris + 3 * j;
         p1 = f4(t[0]); e1 = f4(t[1]); e2 = f4(t[2]);
     }
+    lds_cf4v *sph;
+    __device__ __forceinline__ void sphere(int j, float4 &cr, int &index) const { cr = f4(sph[2 * j]); index = __float_as_int(sph[2 * j + 1].x); }
 };
 
 __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 olo, v3 ohi, v3 inv,
@@ -391,7 +400,7 @@ struct Hit { int id; float t; bool front; v3 normal; uint32_t mat; };
 
 // Scene triangles (SSBO 5) then spheres (SSBO 4), in order, strict `t < closest` (rt.comp:219-230), starting from
 // the closest hit found so far (t, id).
-__device__ __forceinline__ void scene_closest(const SceneView &sc, v3 o, v3 d, float &best_t, int &best_id)
+__device__ __forceinline__ void scene_closest(const SceneView &sc, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres = true)
 {
     for (int i = 0; i < sc.n_tris; i++) {
         const float4 p1 = uniform_load(sc.tri_p1, i), e1 = uniform_load(sc.tri_e1, i), e2 = uniform_load(sc.tri_e2, i);
@@ -399,6 +408,7 @@ __device__ __forceinline__ void scene_closest(const SceneView &sc, v3 o, v3 d, f
         bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
     }
+    if (!with_spheres) return;
     for (int i = 0; i < sc.n_sph; i++) {
         const float4 s = uniform_load(sc.sph, i);
         float t; bool front;
@@ -648,9 +658,11 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 // in `finish`: a scene primitive wins only with a strictly smaller t (rt.comp:213-230 scans the mesh first).
 enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DIR = 5 };
 
-template <class Store>
+// SPH: the scene has a sphere tree (compile-time, so scenes without spheres carry none of its code or registers).
+template <bool SPH, class Store>
 __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
 {
+    const int sph_root = SPH ? sc.sph_root : -1;
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const size_t plane = (size_t)fp.width * fp.height;
     unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
@@ -684,6 +696,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     int s_id = -1, best_id = -1;
     // resumable traversal state: cur >= 0 inner node to visit, cur < 0 inside a leaf at tri_pos .. tri_end
     int cur = 0, sp = 0, tri_pos = 0, tri_end = 0;
+    bool leaf_sph = false;
     v3 inv = V(0, 0, 0);
     float delta = 0.0f;
     int wait = 0;
@@ -734,7 +747,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 // ---- traversal phase
                 wait = 0;
                 PT_COUNT(cyc_gen, 1); PT_COUNT(cyc_mesh, n_mesh);
-                const int exit_at = n_other > 0 ? n_mesh / 4 : 0;
+                const int exit_at = n_other > 0 ? (n_mesh * fp.park_exit) >> 3 : 0;
                 const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
                 const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
                 for (;;) {
@@ -754,7 +767,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             slab_test_fma(a.x, a.y, a.z, a.w, b.x, b.y, nlo, nhi, inv, l0, l1);
                             slab_test_fma(b.z, b.w, c.x, c.y, c.z, c.w, nlo, nhi, inv, r0, r1);
                             const float lim = fmaf(best_t, 1.001f, delta);
-                            const bool hl = l0 <= l1 && l1 >= 0.0f && l0 <= lim, hr = r0 <= r1 && r1 >= 0.0f && r0 <= lim;
+                            // a sphere counts as hit down to t = -HIT_LIMIT (rt.comp:146), hence the slack on the far side
+                            const bool hl = l0 <= l1 && l1 >= -1e-4f && l0 <= lim, hr = r0 <= r1 && r1 >= -1e-4f && r0 <= lim;
                             moved = true;
                             if (hl && hr) {
                                 const bool left_first = l0 <= r0;
@@ -774,7 +788,23 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         }
                     } else {
                         PT_COUNT(cyc_shade, 1);
-                        if (state == S_MESH && cur < 0) {
+                        if (SPH && state == S_MESH && cur < 0 && leaf_sph) {
+                            // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
+                            float4 cr;
+                            int si;
+                            st.sphere(tri_pos, cr, si);
+                            float t; bool front;
+                            const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front);
+                            const int id = sc.n_mesh + sc.n_tris + si;
+                            n_bvh_tests++;
+                            if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+                            tri_pos++;
+                            if (tri_pos == tri_end) {
+                                moved = true;
+                                if (sp == 0) fin = true;
+                                else { sp--; next = (int)stk[sp * kWave]; }
+                            }
+                        } else if (state == S_MESH && cur < 0) {
                             // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
                             const bool two = tri_pos + 1 < tri_end;
                             float4 p1, e1, e2, q1, f1, f2;
@@ -802,14 +832,16 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     }
                     if (moved) {
                         if (fin) {
-                            // merge with the scene primitives: they come later in the reference's scan, so they need a strictly smaller t
-                            if (s_id >= 0 && s_t < best_t) { best_t = s_t; best_id = s_id; }
+                            // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
+                            // the lexicographic minimum of (t, canonical id)
+                            if (s_id >= 0 && (s_t < best_t || (s_t == best_t && s_id < best_id))) { best_t = s_t; best_id = s_id; }
                             state = S_READY;
                         } else if (next >= 0) {
                             cur = next;
                         } else {
                             const int code = ~next;
-                            tri_pos = code >> 3; tri_end = tri_pos + (code & 7) + 1;
+                            leaf_sph = SPH && (code & kSphereLeaf) != 0;
+                            tri_pos = (code & (kSphereLeaf - 1)) >> 3; tri_end = tri_pos + (code & 7) + 1;
                             cur = -1;
                         }
                     }
@@ -909,15 +941,18 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 if (state == S_TRACE) {
                     if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
                     s_t = kInfinity; s_id = -1;
-                    scene_closest(sc, ps.o, ps.d, s_t, s_id);
+                    scene_closest(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
                 }
                 n_seg += __popcll(__ballot(state == S_TRACE));
                 n_mesh_seg += __popcll(__ballot(gate));
                 n_prim_mesh_seg += __popcll(__ballot(gate && ps.bounces == 0));
                 if (state == S_TRACE) {
-                    if (gate) {
+                    if (gate || sph_root >= 0) {
+                        // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
                         state = S_MESH;
-                        cur = 0; sp = 0; best_t = kInfinity; best_id = -1;
+                        sp = 0; best_t = kInfinity; best_id = -1;
+                        cur = gate ? 0 : sph_root;
+                        if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
                         inv = V(__builtin_amdgcn_rcpf(ps.d.x), __builtin_amdgcn_rcpf(ps.d.y), __builtin_amdgcn_rcpf(ps.d.z));
                         delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
@@ -1039,34 +1074,36 @@ __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, u
 
 // BVH traversal variant (any mesh size; the default for meshes of more than one register chunk): persistent 4-wave
 // workgroups, one ray per lane, per-lane traversal stack in LDS (kBvhStack entries x 64 lanes x 4 waves = 40 KB).
-template <int SLOTS>
+template <bool SPH>
 __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp)
 {
     __shared__ unsigned stack[kBvhStack * kLdsBlock];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhStore st;
     st.stack = stack + wave * (kBvhStack * kWave) + lane;
-    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris;
-    trace_items_body_bvh(sc, fp, st, lane);
+    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
+    trace_items_body_bvh<SPH>(sc, fp, st, lane);
 }
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
-// LDS = nodes (64 B each) | triangles (48 B each) | stacks (stack_entries x 4 B x 512 lanes).
+// LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | stacks (stack_entries x 4 B x 512 lanes).
 constexpr int kBvhLdsBlock = 512;
-template <int SLOTS>
+template <bool SPH>
 __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
 {
     extern __shared__ float4 bvh_lds[];
-    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes;
-    unsigned *stack = reinterpret_cast<unsigned *>(tris + 3 * sc.n_mesh);
+    const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
+    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh;
+    unsigned *stack = reinterpret_cast<unsigned *>(sph + n_sph_rec);
     for (int i = threadIdx.x; i < 4 * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
     for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
+    for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhLdsStore st;
     st.stack = stack + wave * (stack_entries * kWave) + lane;
-    st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris;
-    trace_items_body_bvh(sc, fp, st, lane);
+    st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
+    trace_items_body_bvh<SPH>(sc, fp, st, lane);
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
@@ -1127,7 +1164,7 @@ __global__ void __launch_bounds__(kWave) pt_primary_hits_bvh(SceneView sc, Frame
     __shared__ unsigned stack[kBvhStack * kWave];
     BvhStore st;
     st.stack = stack + threadIdx.x;
-    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris;
+    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
     primary_hits_body<SLOTS>(sc, fp, st, threadIdx.x, blockIdx.x);
 }
 
