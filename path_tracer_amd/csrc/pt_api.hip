@@ -294,9 +294,12 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
                 hipLaunchKernelGGL(pt_trace_items_bvh_lds<false>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
             }
         } else if (variant == 5) {
-            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 4);
-            if (c->sph_root >= 0) hipLaunchKernelGGL(pt_trace_items_bvh<true>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
-            else hipLaunchKernelGGL(pt_trace_items_bvh<false>, dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+            // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
+            const size_t lds = (size_t)(c->bvh_depth + 1) * 4 * kLdsBlock;
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));
+            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * per_cu);
+            if (c->sph_root >= 0) hipLaunchKernelGGL(pt_trace_items_bvh<true>, dim3(grid), dim3(kLdsBlock), lds, c->stream, sv, fp, c->bvh_depth + 1);
+            else hipLaunchKernelGGL(pt_trace_items_bvh<false>, dim3(grid), dim3(kLdsBlock), lds, c->stream, sv, fp, c->bvh_depth + 1);
         } else {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);

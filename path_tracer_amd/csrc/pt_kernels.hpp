@@ -382,7 +382,7 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, Store &st, bool
                 float t, det;
                 bool bad = false;
                 bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, bad);
-                if (__builtin_expect(bad, 0)) has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+                if (__builtin_expect(bad, 0)) has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
                 const int id = __float_as_int(p1.w);
                 n_tests++;
                 if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
@@ -815,8 +815,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad);
                             bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad);
                             if (__builtin_expect(bad, 0)) {
-                                has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
-                                has2 = hit_triangle(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2);
+                                has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
+                                has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2);
                             }
                             const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
                             n_bvh_tests += two ? 2 : 1;
@@ -869,7 +869,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             ps.bounces++;
                             const PtMaterial *m = &sc.mats[h.mat];
                             const float m_ior = m->ior, m_smooth = m->smoothness;
-                            const float ior = h.front ? (1.0f / m_ior) : m_ior;
+                            const float ior = h.front ? exact_rcp(m_ior) : m_ior;
                             const bool is_spec = m->specularChance > random_value(ps.rng);
                             const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);
                             const bool is_refr = fres < random_value(ps.rng);
@@ -913,7 +913,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     if (fresh) ps.rng = (uint32_t)(fp.first_pass + k) * pix_seed;       // rt.comp:327
                     const float gx = random_value_nd(ps.rng), gy = random_value_nd(ps.rng), gz = random_value_nd(ps.rng);
                     const v3 g = V(gx, gy, gz);
-                    const float gr = 1.0f / sqrtf(dot(g, g));           // normalize(v) = v * (1/sqrt(dot(v,v)))
+                    const float gr = exact_rcp(sqrtf(dot(g, g)));        // normalize(v) = v * (1/sqrt(dot(v,v)))
                     if (fresh) {
                         // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
                         const v3 jit = (g * 0.00025f) * gr;
@@ -1073,14 +1073,14 @@ __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, u
 }
 
 // BVH traversal variant (any mesh size; the default for meshes of more than one register chunk): persistent 4-wave
-// workgroups, one ray per lane, per-lane traversal stack in LDS (kBvhStack entries x 64 lanes x 4 waves = 40 KB).
+// workgroups, one ray per lane, per-lane traversal stack in LDS.
 template <bool SPH>
-__global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp)
+__global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp, int stack_entries)
 {
-    __shared__ unsigned stack[kBvhStack * kLdsBlock];
+    extern __shared__ unsigned bvh_stack[];      // stack_entries x 4 B x 256 lanes (dynamic: the trees' depth + 1)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhStore st;
-    st.stack = stack + wave * (kBvhStack * kWave) + lane;
+    st.stack = bvh_stack + wave * (stack_entries * kWave) + lane;
     st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
     trace_items_body_bvh<SPH>(sc, fp, st, lane);
 }

@@ -24,7 +24,8 @@ __device__ __forceinline__ v3 operator-(v3 a) { return V(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.z * b.z + a.y * b.y) + a.x * b.x; }
 __device__ __forceinline__ v3 cross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 // normalize(v) = v * (1/sqrt(dot(v,v)))
-__device__ __forceinline__ v3 normalize(v3 v) { float r = 1.0f / sqrtf(dot(v, v)); return v * r; }
+__device__ __forceinline__ float exact_rcp(float x);
+__device__ __forceinline__ v3 normalize(v3 v) { float r = exact_rcp(sqrtf(dot(v, v))); return v * r; }
 // mix(x,y,t) with a dynamic t = x + t*(y-x)
 __device__ __forceinline__ float mixf(float x, float y, float t) { return x + t * (y - x); }
 __device__ __forceinline__ v3 mix3(v3 x, v3 y, float t) { return V(mixf(x.x, y.x, t), mixf(x.y, y.y, t), mixf(x.z, y.z, t)); }
@@ -133,7 +134,6 @@ __device__ __forceinline__ uint32_t pixel_index(int x, int y, float W, float H)
 }
 
 // rt.comp:102-124
-__device__ __forceinline__ float exact_rcp(float x);
 __device__ __forceinline__ bool hit_aabb(v3 bmin, v3 bmax, v3 o, v3 d)
 {
     float ix = exact_rcp(d.x), iy = exact_rcp(d.y), iz = exact_rcp(d.z);      // == 1.0f / d.*, bit for bit
@@ -203,10 +203,18 @@ __device__ __forceinline__ bool hit_triangle_t(v3 p1, v3 e1, v3 e2, v3 o, v3 d, 
     return t > kHitLimit && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
 #endif
 }
-__device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
+__device__ __forceinline__ bool hit_triangle_ieee(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
 {
     bool bad = false;
     return hit_triangle_t<false>(p1, e1, e2, o, d, t_out, det_out, bad);
+}
+// per-lane form: the fast reciprocal where it is exact, the IEEE divide for the lanes where it is not
+__device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
+{
+    bool bad = false;
+    bool has = hit_triangle_t<true>(p1, e1, e2, o, d, t_out, det_out, bad);
+    if (__builtin_expect(bad, 0)) has = hit_triangle_ieee(p1, e1, e2, o, d, t_out, det_out);
+    return has;
 }
 
 // rt.comp:126-146; pow(length(v),2) folds to dot(v,v) and pow(r,2) to r*r in the reference's compiler
