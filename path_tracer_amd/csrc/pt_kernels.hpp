@@ -168,7 +168,7 @@ __device__ __forceinline__ float wave_min_to_lane63(float v)
 //  RegStore: in VGPRs (any mesh size; a mesh of more than one chunk is re-loaded chunk by chunk per ray batch).
 //  LdsStore: in a workgroup-shared LDS image of chunk 0 (meshes of one chunk), read back slot by slot with two
 //            ds_read_b128 + one ds_read_b32 per triangle.  Frees ~100 VGPRs -> more waves per SIMD, which is what
-//            the loop needs: one wave issues a VALU op only every ~5 cycles (tools/slot_bench.hip).
+//            the loop needs: one wave issues a VALU op only every ~5 cycles (tools/loop_bench.hip, tools/valu_mix.hip).
 template <int SLOTS>
 struct RegStore {
     static constexpr bool is_bvh = false;
@@ -1054,22 +1054,40 @@ __global__ void __launch_bounds__(kWave) pt_tile_weights(SceneView sc, FramePara
 // a weight class is whatever the atomics give; nothing depends on it.
 __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, unsigned *order, int *class_count, int n_tiles)
 {
+    constexpr int kPer = (kMaxTileWeight + 1 + 1023) / 1024;          // bins per thread, in descending key order
     __shared__ unsigned hist[kMaxTileWeight + 1];
-    for (int i = threadIdx.x; i <= kMaxTileWeight; i += blockDim.x) hist[i] = 0;
+    __shared__ unsigned part[1024];
+    __shared__ unsigned n_class[2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= kMaxTileWeight; i += 1024) hist[i] = 0;
+    if (tid < 2) n_class[tid] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) atomicAdd(&hist[min(weights[i], (unsigned)kMaxTileWeight)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int w = kMaxTileWeight; w >= 0; w--) {
-            const unsigned n = hist[w]; hist[w] = run; run += n;
-            if (w == 65) class_count[0] = (int)run;                    // keys >= 65: a mesh-gate pixel
-            if (w == 1) class_count[1] = (int)run - class_count[0];    // keys 1..64
-        }
-        class_count[2] = n_tiles - class_count[0] - class_count[1];
+    for (int i = tid; i < n_tiles; i += 1024) {
+        const unsigned w = min(weights[i], (unsigned)kMaxTileWeight);
+        atomicAdd(&hist[w], 1u);
+        if (w >= 65u) atomicAdd(&n_class[0], 1u);                      // keys >= 65: a mesh-gate pixel
+        else if (w >= 1u) atomicAdd(&n_class[1], 1u);                  // keys 1..64: scene primitives only
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) order[atomicAdd(&hist[min(weights[i], (unsigned)kMaxTileWeight)], 1u)] = (unsigned)i;
+    // exclusive prefix over the bins in descending key order: per-thread runs of kPer bins, then a block scan
+    unsigned local = 0;
+    for (int j = 0; j < kPer; j++) { const int b = kMaxTileWeight - (tid * kPer + j); if (b >= 0) local += hist[b]; }
+    part[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const unsigned v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned run = part[tid] - local;
+    for (int j = 0; j < kPer; j++) {
+        const int b = kMaxTileWeight - (tid * kPer + j);
+        if (b >= 0) { const unsigned n = hist[b]; hist[b] = run; run += n; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_tiles; i += 1024) order[atomicAdd(&hist[min(weights[i], (unsigned)kMaxTileWeight)], 1u)] = (unsigned)i;
+    if (tid == 0) { class_count[0] = (int)n_class[0]; class_count[1] = (int)n_class[1]; class_count[2] = n_tiles - (int)n_class[0] - (int)n_class[1]; }
 }
 
 // BVH traversal variant (any mesh size; the default for meshes of more than one register chunk): persistent 4-wave

@@ -327,3 +327,46 @@ def test_config3_1m_triangle_mesh_1080p_windows_vs_oracle(capi):
     b.render(1, 1)
     assert bits_equal(a.read_accum(), b.read_accum())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n_tris", [1, 3, 5])
+def test_bvh_tiny_meshes(capi, cameras, n_tris):
+    """meshes at and below the leaf size (the BVH root is then a stand-in inner node over one leaf)"""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    m = S.heightfield_mesh(4, 1)
+    tris = m.tris[:n_tris].copy()
+    mesh = S.Mesh(tris, S.Mesh.gen_bounding_box(tris), 1)
+    sc = S.default_scene(mesh)
+    sc.add_sphere((0.3, 0.5, 0.2), 0.25, 2)             # one sphere: the sphere tree is a stand-in root too
+    cam = S.Camera(position=np.array([0.2, 1.6, 2.2], np.float32), yaw=95.0, pitch=35.0).UpdateView()
+    W, H = 96, 56
+    want = O.Oracle(sc, cam, W, H, 5).render(1, 3)
+    for variant in (5, 6, 1):
+        r = make(capi, sc, cam, W, H, 5)
+        r.set_tuning(0, 0, 0, variant)
+        r.render(1, 3)
+        assert n_diff_pixels(r.read_accum(), want) == 0, variant
+        r.close()
+
+
+def test_bvh_refuses_non_finite_mesh_and_falls_back(capi, cameras):
+    """a NaN vertex makes the builder refuse the mesh; the library must then trace it by brute force (same image
+    as the oracle, where that triangle simply never hits)"""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    m = S.heightfield_mesh(8, 1)
+    tris = m.tris.copy()
+    tris["p2"][5][1] = np.nan
+    mesh = S.Mesh(tris, S.Mesh.gen_bounding_box(m.tris), 1)
+    sc = S.default_scene(mesh)
+    cam = S.Camera(position=np.array([0.2, 1.6, 2.2], np.float32), yaw=95.0, pitch=35.0).UpdateView()
+    W, H = 64, 40
+    r = make(capi, sc, cam, W, H, 4)
+    r.reset_counters()
+    r.render(1, 2)
+    c = r.counters()
+    assert c["bvh_tri_tests"] == 0 and c["mesh_tri_tests"] > 0, "expected the brute-force kernel"
+    want = O.Oracle(sc, cam, W, H, 4).render(1, 2)
+    assert n_diff_pixels(r.read_accum(), want) == 0
+    r.close()
