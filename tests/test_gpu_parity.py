@@ -370,3 +370,35 @@ def test_bvh_refuses_non_finite_mesh_and_falls_back(capi, cameras):
     want = O.Oracle(sc, cam, W, H, 4).render(1, 2)
     assert n_diff_pixels(r.read_accum(), want) == 0
     r.close()
+
+
+def test_config4_4k_sample_split_emulated_on_one_gpu(capi, cameras, scenes):
+    """BASELINE.json configs[3] (4K, sample split + reduce) with the ranks emulated on one GPU: four contexts trace
+    the pass ranges path_tracer_amd.distributed.pass_range gives ranks 0..3 of a 4-GPU job as plain sums into their
+    own device buffers (torch tensors, as in bench.py), the buffers are summed the way the RCCL reduce sums them,
+    rank 0 scales.  Checked against the oracle's running mean on windows (rtol 1e-5: the summation order differs)."""
+    import torch
+    import oracle_py as O
+    from path_tracer_amd import distributed as D
+    W, H, B, SPP, WORLD = 3840, 2160, 4, 16, 4
+    sc, cam = scenes["default"], cameras["bench"]
+    total = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    covered = []
+    for rank in range(WORLD):
+        first, count = D.pass_range(rank, WORLD, SPP)
+        covered += list(range(first, first + count))
+        buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        r = make(capi, sc, cam, W, H, B)
+        r.set_accum_buffer(buf.data_ptr(), buf.numel() * 4)
+        r.render_sum(first, count)
+        r.synchronize()
+        total += buf                                   # what dist.reduce(SUM) does across ranks
+        r.close()
+    assert covered == list(range(1, SPP + 1))
+    assert D.reduce_and_finish(total, SPP)             # world size 1: no collective, just the finish on "rank 0"
+    got = total.cpu().numpy()
+    assert np.all(got[:, :, 3] == 1.0) and np.isfinite(got).all()
+    o = O.Oracle(sc, cam, W, H, B)
+    for (x0, y0, w, h) in ((1800, 760, 96, 6), (0, 0, 64, 4), (3776, 2156, 64, 4), (2000, 600, 64, 6)):
+        want = o.render_region(1, SPP, x0, y0, w, h)
+        np.testing.assert_allclose(got[y0:y0 + h, x0:x0 + w, :3], want[:, :, :3], rtol=1e-5, atol=1e-6)
