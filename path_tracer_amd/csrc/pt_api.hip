@@ -236,8 +236,15 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     Bind b(c); HIPCHK(c, b.e);
     if ((rc = sync_bvh(c)) != PT_OK) return rc;
     const size_t plane_bytes = (size_t)c->width * c->height * sizeof(float4);
-    const int batch = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, c->workspace_limit / plane_bytes));
-    if (c->radiance.bytes < plane_bytes * batch) {
+    // The traversal kernels (variants 5, 6) schedule lane by lane, so one lane can take ALL passes of a pixel and keep the
+    // running mean in registers: no per-pass workspace, no accumulate kernel.  Only for short pass ranges (interactive
+    // use: one or a few passes per call): a lane task of 64 passes of a hard pixel runs for milliseconds and, started late,
+    // becomes the tail of the launch (measured on config 2: 10.6 ms fused vs 7.8 ms with 4-pass items).
+    const bool allow_fused = !(getenv("PT_NO_FUSED") && atoi(getenv("PT_NO_FUSED")));   // read per call: tests flip it
+    const int variant0 = pick_variant(c);
+    const bool fused = allow_fused && (variant0 == 5 || variant0 == 6) && n_passes <= c->chunk_passes;
+    const int batch = fused ? n_passes : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, c->workspace_limit / plane_bytes));
+    if (!fused && c->radiance.bytes < plane_bytes * batch) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->radiance.release();
         HIPCHK(c, hipMalloc(&c->radiance.p, plane_bytes * batch));
@@ -267,6 +274,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         // passes per item (their items are short, and every item costs one ~11 ns device-wide atomic on the queue)
         static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 16;
         fp.class_ppi[0] = fp.chunk; fp.class_ppi[1] = std::max(1, std::min(np, mul1 * fp.chunk)); fp.class_ppi[2] = std::max(1, std::min(np, mul2 * fp.chunk));
+        if (fused) fp.class_ppi[0] = fp.class_ppi[1] = fp.class_ppi[2] = np;   // SHORT kernels: every item covers all passes
         static const int park_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 40, park_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 2;
         static const int refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 8;
         fp.park_high = park_high; fp.park_wait = park_wait; fp.refill_min = refill_min;
@@ -307,28 +315,32 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         } else if (variant == 6) {
             const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
             const size_t lds = bvh_lds_bytes(c);
-            if (c->sph_root >= 0) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_bvh_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(pt_trace_items_bvh_lds<true>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
-            } else {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_bvh_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(pt_trace_items_bvh_lds<false>, dim3(grid), dim3(kBvhLdsBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
-            }
+            const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_bvh_lds<true, true> : (const void *)&pt_trace_items_bvh_lds<true, false>)
+                                                : (fused ? (const void *)&pt_trace_items_bvh_lds<false, true> : (const void *)&pt_trace_items_bvh_lds<false, false>);
+            HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + 1;
+            void *args[] = {&sv, &fp, &n_nodes, &entries};
+            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
         } else if (variant == 5) {
             // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
             const size_t lds = (size_t)(c->bvh_depth + 1) * 4 * kLdsBlock;
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * per_cu);
-            if (c->sph_root >= 0) hipLaunchKernelGGL(pt_trace_items_bvh<true>, dim3(grid), dim3(kLdsBlock), lds, c->stream, sv, fp, c->bvh_depth + 1);
-            else hipLaunchKernelGGL(pt_trace_items_bvh<false>, dim3(grid), dim3(kLdsBlock), lds, c->stream, sv, fp, c->bvh_depth + 1);
+            const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_bvh<true, true> : (const void *)&pt_trace_items_bvh<true, false>)
+                                                : (fused ? (const void *)&pt_trace_items_bvh<false, true> : (const void *)&pt_trace_items_bvh<false, false>);
+            int entries = c->bvh_depth + 1;
+            void *args[] = {&sv, &fp, &entries};
+            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kLdsBlock), args, lds, c->stream));
         } else {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
-        hipLaunchKernelGGL(pt_accumulate, dim3((fp.traced_width + 255) / 256, fp.rows), dim3(256), 0, c->stream, fp);
-        HIPCHK(c, hipGetLastError());
+        if (!fused) {
+            hipLaunchKernelGGL(pt_accumulate, dim3((fp.traced_width + 255) / 256, fp.rows), dim3(256), 0, c->stream, fp);
+            HIPCHK(c, hipGetLastError());
+        }
         c->n_timed = bi + 1;
     }
     return PT_OK;

@@ -660,7 +660,9 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DIR = 5 };
 
 // SPH: the scene has a sphere tree (compile-time, so scenes without spheres carry none of its code or registers).
-template <bool SPH, class Store>
+// SHORT: launches of a few passes (interactive use): items are dealt round-robin to the waves instead of pulled from the
+// queue, every item covers all passes, and the lane keeps the running mean in registers (no workspace, no pt_accumulate).
+template <bool SPH, bool SHORT, class Store>
 __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
 {
     const int sph_root = SPH ? sc.sph_root : -1;
@@ -681,8 +683,13 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     // one is used up.  So a wave keeps ~64 live paths whatever their lengths, and lanes parked for the mesh can wait for
     // company without idling the others.
     int t_valid = 0, t_next = 0, t_x0 = 0, t_y = 0, t_k0 = 0, t_kend = 0;   // wave-uniform cursor into the current item
+    const int static_stride = (int)(gridDim.x * (blockDim.x / kWave));
+    int static_next = (int)(blockIdx.x + gridDim.x * (threadIdx.x / kWave));   // waves of one workgroup take items far apart in the list
     bool more = true;                                                       // the queue may still hold items
     int x = 0, y = 0, k = 0, k_end = 0;                                     // this lane's pixel and pass range
+    // fused accumulation (SHORT: the lane traces ALL passes of its pixel in order): the running mean lives here
+    v3 acc = V(0, 0, 0);
+    float acc_w = 0.0f;
     uint32_t pix_seed = 0;                                                  // pixelIndex (rt.comp:16); the rng seed is pass * pixelIndex
     float pix_x = 0.0f, pix_y = 0.0f;                                       // pixelPos (rt.comp:14,17)
     // a continuing path between the resolve and direction phases: hit point, normal, refraction index, mix weights
@@ -708,10 +715,17 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             if (more && dead && (__popcll(dead) >= fp.refill_min || !__any(state == S_FRESH || state == S_TRACE || state == S_READY))) {
                 while (dead) {
                     if (t_next >= t_valid) {
-                        // every wave stops fetching once the queue is drained
-                        unsigned fetched = 0;
-                        if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
-                        const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
+                        int item;
+                        if (SHORT) {
+                            // wave w takes items w, w + waves, ... of the heaviest-first list (no queue: one device-wide
+                            // atomic costs ~11 ns serialised, and a 1-spp frame has only ~8 items per wave)
+                            item = static_next; static_next += static_stride;
+                        } else {
+                            // every wave stops fetching once the queue is drained
+                            unsigned fetched = 0;
+                            if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
+                            item = (int)__builtin_amdgcn_readfirstlane(fetched);
+                        }
                         if (item >= n_items) { more = false; break; }
                         // item -> (class, tile rank, pass chunk): classes are contiguous in rank and in item index
                         int rel = item, rank0 = 0, cls = 0;
@@ -732,6 +746,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         pix_seed = pixel_index(x, y, W, H);
                         pix_x = ((((float)x / W) - 0.5f) * W) / H;      // rt.comp:14,17
                         pix_y = ((float)y / H) - 0.5f;
+                        if (SHORT) {
+                            const float4 prev = reinterpret_cast<const float4 *>(fp.accum)[(size_t)y * fp.width + x];
+                            acc = V(prev.x, prev.y, prev.z); acc_w = prev.w;
+                        }
                         state = S_FRESH;
                     }
                     t_next += min(n_dead, room);
@@ -897,9 +915,18 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
                     }
                     if (done) {
-                        fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                        if (SHORT) {
+                            // rt.comp:337-339 in pass order, in registers: accum = mix(accum, colour, 1/pass)
+                            if (fp.sum_mode) acc = acc + colour;
+                            else acc = mix3(acc, colour, exact_rcp((float)(fp.first_pass + k)));
+                        } else {
+                            fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                        }
                         k++;
                         state = k < k_end ? S_FRESH : S_DEAD;
+                        if (SHORT && k == k_end)
+                            reinterpret_cast<float4 *>(fp.accum)[(size_t)y * fp.width + x] =
+                                make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? acc_w + (float)fp.n_passes : 1.0f);
                     }
                 }
             }
@@ -1503,7 +1530,7 @@ __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, u
 
 // BVH traversal variant (any mesh size; the default for meshes of more than one register chunk): persistent 4-wave
 // workgroups, one ray per lane, per-lane traversal stack in LDS.
-template <bool SPH>
+template <bool SPH, bool SHORT>
 __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp, int stack_entries)
 {
     extern __shared__ unsigned bvh_stack[];      // stack_entries x 4 B x 256 lanes (dynamic: the trees' depth + 1)
@@ -1511,13 +1538,13 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
     BvhStore st;
     st.stack = bvh_stack + wave * (stack_entries * kWave) + lane;
     st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
-    trace_items_body_bvh<SPH>(sc, fp, st, lane);
+    trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
 }
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
 // LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | stacks (stack_entries x 4 B x 512 lanes).
 constexpr int kBvhLdsBlock = 512;
-template <bool SPH>
+template <bool SPH, bool SHORT>
 __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
 {
     extern __shared__ float4 bvh_lds[];
@@ -1532,7 +1559,7 @@ __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneV
     BvhLdsStore st;
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
-    trace_items_body_bvh<SPH>(sc, fp, st, lane);
+    trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
 }
 
 // LDS-resident BVH + ray pool shared by the 16 waves of one 1,024-thread workgroup per CU (trace_items_body_pool).

@@ -259,7 +259,7 @@ def test_workspace_batches_and_item_sizes_do_not_change_results(capi, cameras, s
     want = ref.read_accum()
     for chunk, limit in ((1, 0), (3, 0), (64, 0), (4, 3 * W * H * 16), (2, 1)):
         r = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
-        r.set_tuning(chunk, limit)
+        r.set_tuning(chunk, limit, 0, 4)       # brute-force kernel: per-pass workspace + pt_accumulate
         r.render(1, SPP)
         ms, launches = r.last_render_launches()
         assert bits_equal(r.read_accum(), want), (chunk, limit)
@@ -402,3 +402,24 @@ def test_config4_4k_sample_split_emulated_on_one_gpu(capi, cameras, scenes):
     for (x0, y0, w, h) in ((1800, 760, 96, 6), (0, 0, 64, 4), (3776, 2156, 64, 4), (2000, 600, 64, 6)):
         want = o.render_region(1, SPP, x0, y0, w, h)
         np.testing.assert_allclose(got[y0:y0 + h, x0:x0 + w, :3], want[:, :, :3], rtol=1e-5, atol=1e-6)
+
+
+def test_fused_accumulation_equals_workspace_path(capi, cameras, scenes, monkeypatch):
+    """the traversal kernels keep the running mean in registers (one lane = all passes of a pixel); with PT_NO_FUSED=1
+    they write per-pass radiance and pt_accumulate folds it: same image bit for bit, also when a render continues an
+    earlier one (first_pass > 1) and in sum mode"""
+    W, H = 160, 88
+    imgs = {}
+    for no_fused in ("0", "1"):
+        monkeypatch.setenv("PT_NO_FUSED", no_fused)
+        r = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
+        r.render(1, 5)
+        r.render(6, 3)
+        a = r.read_accum()
+        r.reset()
+        r.render_sum(2, 4)
+        r.render_sum(6, 2)
+        imgs[no_fused] = (a, r.read_accum(), r.last_render_launches()[1])
+        r.close()
+    assert bits_equal(imgs["0"][0], imgs["1"][0]) and bits_equal(imgs["0"][1], imgs["1"][1])
+    assert np.all(imgs["0"][1][:, :, 3] == 6.0)
