@@ -134,6 +134,12 @@ int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
  * 7 = experimental: as 6 with the parked rays pooled across the 16 waves of one workgroup per CU (LDS ring; same results,
  * currently ~8 % slower than 6 on config 2). */
 int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
+/* Host-only (no HIP device needed; for tests and tools): build the library's BVH over `tris` exactly as pt_upload_mesh
+ * does and verify it -- every triangle in exactly one leaf, every leaf of 1..8 triangles, every child box containing its
+ * whole subtree, depth within the traversal stack.  Outputs (any may be NULL): inner nodes, depth, largest leaf, SAH cost
+ * relative to the root box.  Returns PT_OK, PT_E_INVALID (bad arguments / non-finite coordinates, which pt_upload_mesh
+ * answers by falling back to brute force) or PT_E_STATE (a check failed: a bug). */
+int pt_bvh_selftest(const PtTriangle *tris, int n_tris, int *n_nodes, int *depth, int *max_leaf, float *sah_cost);
 /* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
 const char *pt_kernel_name(void);
 int pt_version(void);

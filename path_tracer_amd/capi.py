@@ -21,7 +21,7 @@ SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
     "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
-    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_kernel_name",
+    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_bvh_selftest", "pt_kernel_name",
     "pt_version",
 ]
 
@@ -78,6 +78,7 @@ def load():
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
     L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32, i32]
+    L.pt_bvh_selftest.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
     L.pt_kernel_name.restype = C.c_char_p
     L.pt_version.restype = i32
     _lib = L
@@ -189,3 +190,12 @@ class Renderer:
 
     def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0, waves_per_cu=0, variant=0):
         self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes, waves_per_cu, variant))
+
+
+def bvh_selftest(tris):
+    """Host-only: build + verify the library's BVH over a TRIANGLE_DTYPE array; returns (rc, nodes, depth, max_leaf, sah)."""
+    L = load()
+    t = np.ascontiguousarray(tris)
+    a, b, c, f = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+    rc = L.pt_bvh_selftest(t.ctypes.data, len(t), C.byref(a), C.byref(b), C.byref(c), C.byref(f))
+    return rc, a.value, b.value, c.value, f.value

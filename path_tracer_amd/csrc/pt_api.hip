@@ -709,6 +709,63 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
     return PT_OK;
 }
 
+int pt_bvh_selftest(const PtTriangle *tris, int n, int *n_nodes, int *depth, int *max_leaf, float *sah_cost)
+{
+    if (!tris || n < 1) return PT_E_INVALID;
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            if (!std::isfinite(tris[i].p1[k]) || !std::isfinite(tris[i].p2[k]) || !std::isfinite(tris[i].p3[k])) return PT_E_INVALID;
+    Bvh bvh;
+    build_bvh(tris, n, bvh);
+    if (bvh.nodes.empty() || (int)bvh.order.size() != n || bvh.depth > kBvhMaxDepth) return PT_E_STATE;
+    std::vector<int> seen(n, 0);
+    int biggest = 0, deepest = 0;
+    double cost = 0.0;
+    bool ok = true;
+    // returns the box of the subtree under `code`, checking containment on the way up
+    struct Walker {
+        const Bvh &b; const PtTriangle *tris; int n; std::vector<int> &seen; int &biggest, &deepest; double &cost; bool &ok;
+        bvh_detail::Box walk(int code, int d)
+        {
+            bvh_detail::Box box; box.reset();
+            if (d > kBvhMaxDepth + 1) { ok = false; return box; }
+            deepest = std::max(deepest, d);
+            if (code < 0) {
+                const int c = ~code, first = c >> 3, cnt = (c & 7) + 1;
+                if ((c & kSphereLeaf) || first < 0 || first + cnt > n) { ok = false; return box; }
+                biggest = std::max(biggest, cnt);
+                for (int j = first; j < first + cnt; j++) {
+                    const int i = b.order[j];
+                    if (i < 0 || i >= n) { ok = false; return box; }
+                    seen[i]++;
+                    box.grow(tris[i].p1); box.grow(tris[i].p2); box.grow(tris[i].p3);
+                }
+                cost += box.half_area() * cnt;
+                return box;
+            }
+            if (code >= (int)b.nodes.size()) { ok = false; return box; }
+            const BvhNode &nd = b.nodes[code];
+            const bvh_detail::Box l = walk(nd.left, d + 1), r = walk(nd.right, d + 1);
+            for (int k = 0; k < 3; k++) {
+                if (!(nd.lmin[k] <= l.mn[k] && nd.lmax[k] >= l.mx[k] && nd.rmin[k] <= r.mn[k] && nd.rmax[k] >= r.mx[k])) ok = false;
+            }
+            box.grow(l); box.grow(r);
+            cost += box.half_area();
+            return box;
+        }
+    } w{bvh, tris, n, seen, biggest, deepest, cost, ok};
+    const bvh_detail::Box root = w.walk(0, 0);
+    // a mesh of <= kLeafMax triangles has a stand-in root whose two children are the same leaf: each triangle is seen twice
+    const int expect = n <= kLeafMax ? 2 : 1;
+    for (int i = 0; i < n; i++) if (seen[i] != expect) ok = false;
+    if (!ok) return PT_E_STATE;
+    if (n_nodes) *n_nodes = (int)bvh.nodes.size();
+    if (depth) *depth = bvh.depth;
+    if (max_leaf) *max_leaf = biggest;
+    if (sah_cost) *sah_cost = root.half_area() > 0.0f ? (float)(cost / root.half_area()) : 0.0f;
+    return PT_OK;
+}
+
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;

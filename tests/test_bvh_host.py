@@ -1,0 +1,59 @@
+"""Host-side BVH builder of libpt_hip.so (path_tracer_amd/csrc/pt_bvh.hpp), exercised without a GPU through
+pt_bvh_selftest: structure invariants the traversal kernel relies on."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from path_tracer_amd import capi as c
+    c.load()
+    return c
+
+
+def test_bunny(capi):
+    from path_tracer_amd import scene as S
+    m = S.bunny_mesh(3)
+    rc, nodes, depth, max_leaf, sah = capi.bvh_selftest(m.tris)
+    assert rc == 0
+    assert 1 <= max_leaf <= 4 and len(m.tris) / 4 <= nodes + 1 <= len(m.tris)
+    assert depth <= 24, "a 656-triangle mesh must not come near the 40-entry traversal stack"
+    assert 0 < sah < 60
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 5, 9])
+def test_tiny(capi, n):
+    from path_tracer_amd import scene as S
+    t = S.heightfield_mesh(4, 1).tris[:n]
+    rc, nodes, depth, max_leaf, _ = capi.bvh_selftest(t)
+    assert rc == 0 and nodes >= 1 and max_leaf <= 4
+
+
+def test_degenerate_inputs_keep_the_depth_bound(capi):
+    from path_tracer_amd import scene as S
+    # 5000 copies of one triangle: no spatial split exists, the builder must fall back to median splits
+    one = S.heightfield_mesh(1, 1).tris[:1]
+    rc, nodes, depth, max_leaf, _ = capi.bvh_selftest(np.repeat(one, 5000))
+    assert rc == 0 and depth <= 40 and max_leaf <= 4
+    # a long sliver row (all centroids on one line, exponentially growing sizes): SAH makes deep trees, the bound holds
+    t = np.repeat(one, 3000)
+    for k, name in enumerate(("p1", "p2", "p3")):
+        t[name][:, 0] = (1.001 ** np.arange(3000) + 0.01 * k).astype(np.float32)
+        t[name][:, 1] = 0.1 * k
+        t[name][:, 2] = 0.0
+    rc, nodes, depth, max_leaf, _ = capi.bvh_selftest(t)
+    assert rc == 0 and depth <= 40
+
+
+def test_one_million_triangles(capi):
+    from path_tracer_amd import scene as S
+    m = S.heightfield_mesh(708, 3)
+    rc, nodes, depth, max_leaf, sah = capi.bvh_selftest(m.tris)
+    assert rc == 0 and len(m.tris) == 1002528 and depth <= 40 and max_leaf <= 4
+
+
+def test_non_finite_is_refused(capi):
+    from path_tracer_amd import scene as S
+    t = S.heightfield_mesh(4, 1).tris.copy()
+    t["p3"][7][2] = np.inf
+    assert capi.bvh_selftest(t)[0] == capi.PT_E_INVALID
