@@ -3,7 +3,11 @@
 // dispatch), with the window loop replaced by "render --spp passes, write the image".
 //   pt_main --mesh bunny1.obj [--scene default|mixed] [--width 1920 --height 1080] [--spp 64] [--bounces 8]
 //           [--cam x y z yaw pitch] [--debug-normal] [--batch] [--out accum.f32] [--ppm image.ppm] [--device 0]
+//           [--orbit FRAMES DEGREES]   scripted stand-in for the interactive loop (src/Main.cpp:108-150): every frame the
+//                                      camera turns by DEGREES of yaw around the scene centre, which restarts the
+//                                      accumulation (currAccumPass = 0 + clear, src/Main.cpp:110-117), then --spp passes
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +45,7 @@ int main(int argc, char **argv)
     int width = 1920, height = 1080, spp = 64, bounces = 8, device = 0;
     bool debugNormal = false, batch = false, cam_given = false, print_camera = false;
     float cam[5] = {1.5f, 0.4f, 0.0f, 0.0f, 0.0f};
+    int orbit_frames = 0; float orbit_deg = 0.0f;
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (!std::strcmp(argv[i], "--mesh")) mesh_path = next();
@@ -55,6 +60,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--debug-normal")) debugNormal = true;
         else if (!std::strcmp(argv[i], "--batch")) batch = true;
         else if (!std::strcmp(argv[i], "--print-camera")) print_camera = true;
+        else if (!std::strcmp(argv[i], "--orbit")) { orbit_frames = std::atoi(next()); orbit_deg = std::strtof(next(), nullptr); }
         else if (!std::strcmp(argv[i], "--cam")) { for (int k = 0; k < 5; k++) cam[k] = std::strtof(next(), nullptr); cam_given = true; }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -94,7 +100,28 @@ int main(int argc, char **argv)
     computeProgram.SetUniformCamera(Renderer::camera);
 
     const auto t0 = std::chrono::steady_clock::now();
-    if (batch) {
+    if (orbit_frames > 0) {
+        // the camera moves every frame: like the reference while a key is held, each frame starts a new accumulation
+        const float radius = std::sqrt(cam[0] * cam[0] + cam[2] * cam[2]);
+        const float start = std::atan2(cam[2], cam[0]);
+        for (int frame = 1; frame <= orbit_frames; frame++) {
+            const float a = start + radians(orbit_deg * (float)frame);
+            Renderer::camera.position = vec3(radius * std::cos(a), cam[1], radius * std::sin(a));
+            Renderer::camera.yaw = cam[3] + orbit_deg * (float)frame;       // keeps looking at the y axis
+            Renderer::camera.UpdateView();
+            if (!Renderer::Check(pt_reset(Renderer::ctx), "pt_reset")) return 1;
+            for (int currAccumPass = 1; currAccumPass <= spp; currAccumPass++) {
+                computeProgram.SetUniform1i("currAccumPass", currAccumPass);
+                computeProgram.SetUniformCamera(Renderer::camera);
+                computeProgram.Dispatch();
+            }
+        }
+        if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("Frames: %d x %d spp | %.3f ms per frame | %.1f frames/s | final camera %.9g %.9g %.9g yaw %.9g\n", orbit_frames, spp,
+                    dt * 1e3 / orbit_frames, orbit_frames / dt, Renderer::camera.position.x, Renderer::camera.position.y,
+                    Renderer::camera.position.z, Renderer::camera.yaw);
+    } else if (batch) {
         if (!Renderer::Check(pt_render(Renderer::ctx, 1, spp), "pt_render")) return 1;
     } else {
         int currAccumPass = 0;
@@ -106,8 +133,10 @@ int main(int argc, char **argv)
         }
     }
     if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
-    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("Samples: %d | %.3f ms | %.1f Msamples/s\n", spp, dt * 1e3, (double)width * height * spp / dt * 1e-6);
+    if (orbit_frames <= 0) {
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("Samples: %d | %.3f ms | %.1f Msamples/s\n", spp, dt * 1e3, (double)width * height * spp / dt * 1e-6);
+    }
 
     if (!out_path.empty()) {
         std::vector<float> img((size_t)width * height * 4);

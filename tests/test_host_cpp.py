@@ -64,3 +64,22 @@ def test_pt_main_mixed_scene(tmp_path, meta):
                     "--batch", "--out", str(out)], check=True, capture_output=True, timeout=120)
     img = np.fromfile(out, np.float32).reshape(360, 640, 4)
     assert crc(img[:, :, :3]) == meta["radiance_mixed_b16_640x360"]["crc_mean4"]
+
+
+@pytest.mark.gpu
+def test_pt_main_scripted_camera_loop(tmp_path):
+    """the interactive loop's stand-in (src/Main.cpp:108-150): the camera moves every frame, each frame restarts the
+    accumulation (pt_reset) and renders 2 passes with the short-launch kernels; the last frame must be the image a fresh
+    process renders from that final camera pose"""
+    import re
+    obj, a, b = tmp_path / "bunny1.obj", tmp_path / "orbit.f32", tmp_path / "still.f32"
+    _write_obj(obj)
+    common = [PT_MAIN, "--mesh", str(obj), "--width", "320", "--height", "184", "--spp", "2", "--bounces", "4"]
+    r = subprocess.run(common + ["--orbit", "5", "7.5", "--out", str(a)], check=True, capture_output=True, text=True, timeout=120)
+    m = re.search(r"Frames: 5 x 2 spp .* final camera (\S+) (\S+) (\S+) yaw (\S+)", r.stdout)
+    assert m, r.stdout
+    x, y, z, yaw = m.groups()
+    subprocess.run(common + ["--cam", x, y, z, yaw, "0", "--out", str(b)], check=True, capture_output=True, timeout=120)
+    ia, ib = np.fromfile(a, np.float32), np.fromfile(b, np.float32)
+    assert ia.size == 320 * 184 * 4 and np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
+    assert float(ia.reshape(184, 320, 4)[:, :, :3].max()) > 0
