@@ -130,9 +130,7 @@ int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
  * variant: 1 = brute force, mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = brute force, resident in a
  * workgroup-shared LDS image at 4 / 5 / 6 waves per SIMD (meshes of at most 704 triangles; default for those),
  * 5 = BVH traversal, one ray per lane, BVH in global memory (any mesh size), 6 = the same with the BVH staged into
- * LDS (default; falls back to 5 when nodes + triangles + stacks exceed 80 KB; see DESIGN.md for its exactness),
- * 7 = experimental: as 6 with the parked rays pooled across the 16 waves of one workgroup per CU (LDS ring; same results,
- * currently ~8 % slower than 6 on config 2). */
+ * LDS (default; falls back to 5 when nodes + triangles + stacks exceed 80 KB; see DESIGN.md for its exactness). */
 int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
 /* Host-only (no HIP device needed; for tests and tools): build the library's BVH over `tris` exactly as pt_upload_mesh
  * does and verify it -- every triangle in exactly one leaf, every leaf of 1..8 triangles, every child box containing its

@@ -208,21 +208,12 @@ int sync_bvh(pt_ctx *c)
     return PT_OK;
 }
 
-// LDS of the pooled kernel (one 1,024-thread workgroup per CU).
-constexpr size_t kPoolLdsLimit = 156 * 1024;
-size_t pool_lds_bytes(const pt_ctx *c)
-{
-    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)(c->bvh_depth + 1) * 4 * kPoolBlock
-           + (size_t)kPoolCap * 28 + (size_t)kPoolBlock * 8 + 16;
-}
-
 // Kernel variant for the uploaded mesh.  Default: the BVH traversal whenever the builder accepted the mesh; brute
 // force from the LDS image (one register chunk) or from VGPRs otherwise, or when asked for through pt_set_tuning.
 int pick_variant(const pt_ctx *c)
 {
     int variant = c->variant ? c->variant : PT_DEFAULT_VARIANT;
     if (variant >= 5 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
-    if (variant == 7 && pool_lds_bytes(c) > kPoolLdsLimit) variant = 6;
     if (variant == 6 && bvh_lds_bytes(c) > kBvhLdsLimit) variant = 5;     // too large for two workgroups per CU
     if (variant >= 2 && variant <= 4 && c->n_chunks != 1) variant = 1;    // the LDS image holds exactly one chunk
     return variant;
@@ -300,18 +291,6 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         } else if (variant == 3) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 5);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
-        } else if (variant == 7) {
-            const unsigned grid = (unsigned)std::min<long long>((items + 15) / 16, (long long)c->n_cus);
-            const size_t lds = pool_lds_bytes(c);
-            static const int session_max = getenv("PT_POOL_SESSION") ? atoi(getenv("PT_POOL_SESSION")) : 256;
-            fp.pool_session_max = session_max;
-            if (c->sph_root >= 0) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_pool<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(pt_trace_items_pool<true>, dim3(grid), dim3(kPoolBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
-            } else {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pt_trace_items_pool<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(pt_trace_items_pool<false>, dim3(grid), dim3(kPoolBlock), lds, c->stream, sv, fp, c->bvh_n_nodes, c->bvh_depth + 1);
-            }
         } else if (variant == 6) {
             const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
             const size_t lds = bvh_lds_bytes(c);
@@ -769,7 +748,7 @@ int pt_bvh_selftest(const PtTriangle *tris, int n, int *n_nodes, int *depth, int
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;
-    if (variant < 0 || variant > 7) return fail(c, PT_E_INVALID, "variant outside [0,7]");
+    if (variant < 0 || variant > 6) return fail(c, PT_E_INVALID, "variant outside [0,6]");
     if (variant) c->variant = variant;
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
     if (waves_per_cu) c->waves_per_cu = waves_per_cu;

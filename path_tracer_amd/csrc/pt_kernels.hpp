@@ -76,7 +76,6 @@ struct FrameParams {
     int park_high, park_wait; // BVH body: traverse when this many lanes are parked, or after this many iterations of waiting
     int refill_min;           // BVH body: hand out new pixels once this many lanes are idle
     int park_exit;            // BVH body: leave the traversal phase when park_exit/8 of its rays are still unfinished
-    int pool_session_max;     // pooled body: rays one consumer session may claim before it only drains
     int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
                                     // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span [10] BVH node visits [11] BVH triangle tests
@@ -1014,416 +1013,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same body with the parked rays POOLED ACROSS THE WAVES OF A WORKGROUP (LDS ring): a lane whose ray needs the
-// trees publishes it (origin, direction, owner) and waits in S_WAIT; any wave of the workgroup that sees enough pending
-// rays claims up to 64 of them (one compare-and-swap on the ring's head), traverses them with every lane busy, tops
-// its free lanes up from the ring while it goes, and posts each result to the owner's mailbox.  A workgroup of 1,024
-// lanes produces ~90 such rays per iteration on config 2, so traversal batches are full where one wave alone collects
-// ~5 per iteration.  No barriers and no unbounded waits: producers never block, a consumer depends on nobody, a wave
-// with nothing else to do consumes whatever is pending, and both spin loops are bounded (a timeout raises
-// counters[3] and resolves the ray as a miss instead of hanging the GPU).
-struct RayPool {
-    float *ray;          // [6][kPoolCap] SoA: origin xyz, direction xyz
-    unsigned *tag;       // [kPoolCap] generation << 16 | gate << 15 | owner thread, written last (release)
-    unsigned *ctl;       // [0] tail (slots reserved), [1] head (slots claimed)
-    float *res_t;        // [workgroup lanes] mailbox: closest t ...
-    int *res_id;         // ... and canonical id of the pooled traversal; kNotReady until it is posted (release)
-};
-constexpr int kPoolCap = 1024;            // >= lanes per workgroup: a lane has at most one ray outstanding
-constexpr int kNotReady = 0x7ffffff0;
-constexpr int kIdle = (int)0x80000000;    // consumer lane holds no ray
-constexpr int S_WAIT = 6;
-
-template <bool SPH, class Store>
-__device__ __forceinline__ void trace_items_body_pool(const SceneView &sc, const FrameParams &fp, Store &st, const RayPool &pool, int lane, int tid)
-{
-    const int sph_root = SPH ? sc.sph_root : -1;
-    const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
-    const size_t plane = (size_t)fp.width * fp.height;
-    unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
-    unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
-    unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
-    const unsigned long long t_start = wall_clock64();
-    const int count0 = fp.class_count[0], count1 = fp.class_count[1], count2 = fp.class_count[2];
-    const int per_tile0 = (fp.n_passes + fp.class_ppi[0] - 1) / fp.class_ppi[0], per_tile1 = (fp.n_passes + fp.class_ppi[1] - 1) / fp.class_ppi[1],
-              per_tile2 = (fp.n_passes + fp.class_ppi[2] - 1) / fp.class_ppi[2];
-    const int items0 = count0 * per_tile0, items1 = count1 * per_tile1;
-    const int n_items = items0 + items1 + count2 * per_tile2;
-    unsigned *stk = st.stack;
-    // Lanes are scheduled one by one: a lane that has finished its pixel takes the next unassigned pixel of the wave's
-    // current work item (64 px of a row x a range of passes), and the wave fetches another item from the queue when that
-    // one is used up.  So a wave keeps ~64 live paths whatever their lengths, and lanes parked for the mesh can wait for
-    // company without idling the others.
-    int t_valid = 0, t_next = 0, t_x0 = 0, t_y = 0, t_k0 = 0, t_kend = 0;   // wave-uniform cursor into the current item
-    bool more = true;                                                       // the queue may still hold items
-    int x = 0, y = 0, k = 0, k_end = 0;                                     // this lane's pixel and pass range
-    uint32_t pix_seed = 0;                                                  // pixelIndex (rt.comp:16); the rng seed is pass * pixelIndex
-    float pix_x = 0.0f, pix_y = 0.0f;                                       // pixelPos (rt.comp:14,17)
-    // a continuing path between the resolve and direction phases: hit point, normal, refraction index, mix weights
-    v3 hp = V(0, 0, 0), nrm = V(0, 0, 0);
-    float eta = 1.0f, mix_a = 0.0f, mix_b = 0.0f;
-    bool refr = false;
-    int state = S_DEAD;
-    PathState ps;
-    ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
-    // closest hit: scene primitives (s_t, s_id); mesh traversal / final result (best_t, best_id)
-    float s_t = kInfinity, best_t = kInfinity;
-    int s_id = -1, best_id = -1;
-    // consumer side (a ray claimed from the pool, not this lane's own): cur >= 0 inner node to visit, cur == -1 inside a
-    // leaf at tri_pos .. tri_end, cur == kIdle no ray
-    int cur = kIdle, sp = 0, tri_pos = 0, tri_end = 0, owner = 0;
-    bool leaf_sph = false;
-    v3 r_o = V(0, 0, 0), r_d = V(0, 0, 0), inv = V(0, 0, 0), nlo = V(0, 0, 0), nhi = V(0, 0, 0);
-    float delta = 0.0f;
-    int waited = 0;
-    {
-        for (;;) {
-            // ---- refill dead lanes with the next pixels
-            unsigned long long dead = __ballot(state == S_DEAD);
-            if (more && dead && (__popcll(dead) >= fp.refill_min || !__any(state == S_FRESH || state == S_TRACE || state == S_READY))) {
-                while (dead) {
-                    if (t_next >= t_valid) {
-                        // every wave stops fetching once the queue is drained
-                        unsigned fetched = 0;
-                        if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
-                        const int item = (int)__builtin_amdgcn_readfirstlane(fetched);
-                        if (item >= n_items) { more = false; break; }
-                        // item -> (class, tile rank, pass chunk): classes are contiguous in rank and in item index
-                        int rel = item, rank0 = 0, cls = 0;
-                        if (rel >= items0) { rel -= items0; rank0 = count0; cls = 1; if (rel >= items1) { rel -= items1; rank0 += count1; cls = 2; } }
-                        const int per_tile = cls == 0 ? per_tile0 : cls == 1 ? per_tile1 : per_tile2;
-                        const int ppi = fp.class_ppi[cls];
-                        const int chunk = rel % per_tile;
-                        const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
-                        t_x0 = (tile % fp.x_blocks) * kWave; t_y = tile / fp.x_blocks;
-                        t_k0 = chunk * ppi; t_kend = min(fp.n_passes, (chunk + 1) * ppi);
-                        t_valid = min(kWave, fp.traced_width - t_x0); t_next = 0;
-                    }
-                    const int n_dead = __popcll(dead), room = t_valid - t_next;
-                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dead, 0));   // dead lanes below this one
-                    if (state == S_DEAD && rank < room) {
-                        x = t_x0 + t_next + rank; y = t_y; k = t_k0; k_end = t_kend;
-                        const float W = (float)fp.width, H = (float)fp.height;
-                        pix_seed = pixel_index(x, y, W, H);
-                        pix_x = ((((float)x / W) - 0.5f) * W) / H;      // rt.comp:14,17
-                        pix_y = ((float)y / H) - 0.5f;
-                        state = S_FRESH;
-                    }
-                    t_next += min(n_dead, room);
-                    dead = __ballot(state == S_DEAD);
-                }
-            }
-            // ---- mailbox: results for the rays this wave's lanes have published
-            if (__any(state == S_WAIT)) {
-                if (state == S_WAIT) {
-                    const int rid = __hip_atomic_load(&pool.res_id[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (rid != kNotReady) {
-                        const float rt = pool.res_t[tid];
-                        // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
-                        // the lexicographic minimum of (t, canonical id)
-                        if (!(s_id >= 0 && (s_t < rt || (s_t == rt && s_id < rid)))) { s_t = rt; s_id = rid; }
-                        state = S_READY;
-                    } else if (++waited > (1 << 18)) {
-                        if (fp.counters) atomicAdd(&fp.counters[3], 1ull);      // lost ray: never expected
-                        state = S_READY;
-                    }
-                }
-            }
-            const unsigned long long m_mesh = __ballot(state == S_WAIT);
-            const unsigned long long m_other = __ballot(state == S_FRESH || state == S_TRACE || state == S_READY);   // S_DIR never survives an iteration
-            if (!(m_mesh | m_other)) break;      // nothing alive and (refill ran) nothing left in the queue
-            n_iter++;
-            const int n_mesh = __popcll(m_mesh), n_other = __popcll(m_other);
-            PT_TICK(c0);
-            // ---- consumer session
-            const int pending = (int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                                      - __builtin_amdgcn_readfirstlane(__hip_atomic_load(&pool.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-            if (pending >= fp.park_high || (n_other == 0 && pending > 0)) {
-                PT_COUNT(cyc_gen, 1);
-                int claimed = 0, step = 0;
-                for (;;) {
-                    const unsigned long long act = __ballot(cur != kIdle);
-                    const int n_act = __popcll(act);
-                    if (n_act == 0 || (n_act <= 48 && (step & 7) == 0 && claimed < fp.pool_session_max)) {
-                        unsigned h = 0, n = 0;
-                        if (claimed < fp.pool_session_max && lane == 0) {
-                            const int want = kWave - n_act, need = n_act == 0 ? 1 : 16;
-                            for (int tries = 0; tries < 4; tries++) {
-                                const unsigned hd = __hip_atomic_load(&pool.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                const unsigned tl = __hip_atomic_load(&pool.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                const int avail = (int)(tl - hd);
-                                if (avail < need) break;
-                                const unsigned take = (unsigned)min(avail, want);
-                                unsigned expected = hd;
-                                if (__hip_atomic_compare_exchange_strong(&pool.ctl[1], &expected, hd + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { h = hd; n = take; break; }
-                            }
-                        }
-                        h = __builtin_amdgcn_readfirstlane(h); n = __builtin_amdgcn_readfirstlane(n);
-                        if (n) {
-                            PT_COUNT(cyc_mesh, n);
-                            claimed += (int)n;
-                            const unsigned long long free_m = ~act;
-                            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_m, 0));   // free lanes below this one
-                            if (cur == kIdle && rank < n) {
-                                const unsigned sa = h + rank, slot = sa & (kPoolCap - 1), gen = ((sa / kPoolCap) + 1) & 0xffffu;
-                                unsigned tag;
-                                int spins = 0;
-                                do { tag = __hip_atomic_load(&pool.tag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); } while ((tag >> 16) != gen && ++spins < (1 << 20));
-                                if ((tag >> 16) == gen) {
-                                    owner = (int)(tag & 0x7fffu);
-                                    const bool gate = (tag & 0x8000u) != 0;
-                                    r_o = V(pool.ray[0 * kPoolCap + slot], pool.ray[1 * kPoolCap + slot], pool.ray[2 * kPoolCap + slot]);
-                                    r_d = V(pool.ray[3 * kPoolCap + slot], pool.ray[4 * kPoolCap + slot], pool.ray[5 * kPoolCap + slot]);
-                                    // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
-                                    inv = V(__builtin_amdgcn_rcpf(r_d.x), __builtin_amdgcn_rcpf(r_d.y), __builtin_amdgcn_rcpf(r_d.z));
-                                    delta = 4e-6f * ((fabsf(r_o.x) + fabsf(r_o.y)) + (fabsf(r_o.z) + sc.bvh_scale));
-                                    nlo = V(-((r_o.x + delta) * inv.x), -((r_o.y + delta) * inv.y), -((r_o.z + delta) * inv.z));
-                                    nhi = V(-((r_o.x - delta) * inv.x), -((r_o.y - delta) * inv.y), -((r_o.z - delta) * inv.z));
-                                    // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
-                                    sp = 0; best_t = kInfinity; best_id = -1;
-                                    cur = gate ? 0 : sph_root;
-                                    if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
-                                } else if (fp.counters) {
-                                    atomicAdd(&fp.counters[3], 1ull);           // slot never published: never expected
-                                }
-                            }
-                        } else if (n_act == 0) {
-                            break;
-                        }
-                    }
-                    step++;
-                    const int n = __popcll(__ballot(cur != kIdle));
-                    const int n_node = __popcll(__ballot(cur >= 0));
-                    int next = 0;
-                    bool moved = false, fin = false;       // lane got a new node/leaf code in `next`, or finished its ray
-                    if (2 * n_node >= n) {
-                        PT_COUNT(cyc_trace, 1);
-                        if (cur >= 0) {
-                            float4 a, b, c;
-                            int kl, kr;
-                            st.node(cur, a, b, c, kl, kr);
-                            n_bvh_nodes++;
-                            float l0, l1, r0, r1;
-                            slab_test_fma(a.x, a.y, a.z, a.w, b.x, b.y, nlo, nhi, inv, l0, l1);
-                            slab_test_fma(b.z, b.w, c.x, c.y, c.z, c.w, nlo, nhi, inv, r0, r1);
-                            const float lim = fmaf(best_t, 1.001f, delta);
-                            // a sphere counts as hit down to t = -HIT_LIMIT (rt.comp:146), hence the slack on the far side
-                            const bool hl = l0 <= l1 && l1 >= -1e-4f && l0 <= lim, hr = r0 <= r1 && r1 >= -1e-4f && r0 <= lim;
-                            moved = true;
-                            if (hl && hr) {
-                                const bool left_first = l0 <= r0;
-                                next = left_first ? kl : kr;
-                                stk[sp * kWave] = (unsigned)(left_first ? kr : kl);
-                                sp++;
-                            } else if (hl) {
-                                next = kl;
-                            } else if (hr) {
-                                next = kr;
-                            } else if (sp == 0) {
-                                fin = true;
-                            } else {
-                                sp--;
-                                next = (int)stk[sp * kWave];
-                            }
-                        }
-                    } else {
-                        PT_COUNT(cyc_shade, 1);
-                        if (SPH && cur == -1 && leaf_sph) {
-                            // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
-                            float4 cr;
-                            int si;
-                            st.sphere(tri_pos, cr, si);
-                            float t; bool front;
-                            const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, r_o, r_d, t, front);
-                            const int id = sc.n_mesh + sc.n_tris + si;
-                            n_bvh_tests++;
-                            if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                            tri_pos++;
-                            if (tri_pos == tri_end) {
-                                moved = true;
-                                if (sp == 0) fin = true;
-                                else { sp--; next = (int)stk[sp * kWave]; }
-                            }
-                        } else if (cur == -1) {
-                            // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
-                            const bool two = tri_pos + 1 < tri_end;
-                            float4 p1, e1, e2, q1, f1, f2;
-                            st.tri(tri_pos, p1, e1, e2);
-                            st.tri(two ? tri_pos + 1 : tri_pos, q1, f1, f2);
-                            float t, det, t2, det2;
-                            bool bad = false;
-                            bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), r_o, r_d, t, det, bad);
-                            bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), r_o, r_d, t2, det2, bad);
-                            if (__builtin_expect(bad, 0)) {
-                                has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), r_o, r_d, t, det);
-                                has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), r_o, r_d, t2, det2);
-                            }
-                            const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
-                            n_bvh_tests += two ? 2 : 1;
-                            if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                            if (two && has2 && (t2 < best_t || (t2 == best_t && id2 < best_id))) { best_t = t2; best_id = id2; }
-                            tri_pos += two ? 2 : 1;
-                            if (tri_pos == tri_end) {
-                                moved = true;
-                                if (sp == 0) fin = true;
-                                else { sp--; next = (int)stk[sp * kWave]; }
-                            }
-                        }
-                    }
-                    if (moved) {
-                        if (fin) {
-                            pool.res_t[owner] = best_t;
-                            __hip_atomic_store(&pool.res_id[owner], best_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            cur = kIdle;
-                        } else if (next >= 0) {
-                            cur = next;
-                        } else {
-                            const int code = ~next;
-                            leaf_sph = SPH && (code & kSphereLeaf) != 0;
-                            tri_pos = (code & (kSphereLeaf - 1)) >> 3; tri_end = tri_pos + (code & 7) + 1;
-                            cur = -1;
-                        }
-                    }
-                }
-            } else if (n_other == 0) {
-                __builtin_amdgcn_s_sleep(8);       // every lane waits for a result another wave is computing
-            }
-            PT_TICK(c1);
-            PT_ACC(cyc_mesh, c0, c1);
-            // ---- resolve phase (rt.comp:273-322), up to the point where a continuing path needs its random direction
-            if (__any(state == S_READY)) {
-                n_hits += __popcll(__ballot(state == S_READY && s_id >= 0 && s_t < kInfinity && !fp.debug_normal));
-                if (state == S_READY) {
-                    Hit h;
-                    h.id = s_id; h.t = s_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
-                    finish_hit(sc, ps.o, ps.d, h);
-                    const bool hit = h.id >= 0 && h.t < kInfinity;
-                    bool done = true;
-                    v3 colour;
-                    if (hit && fp.debug_normal) {
-                        colour = h.normal;                              // rt.comp:274
-                    } else {
-                        if (hit) {
-                            // rt.comp:276-311; the draws keep the shader's order: specular, refraction, then the direction
-                            ps.bounces++;
-                            const PtMaterial *m = &sc.mats[h.mat];
-                            const float m_ior = m->ior, m_smooth = m->smoothness;
-                            const float ior = h.front ? exact_rcp(m_ior) : m_ior;
-                            const bool is_spec = m->specularChance > random_value(ps.rng);
-                            const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);
-                            const bool is_refr = fres < random_value(ps.rng);
-                            const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
-                            const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
-                            ps.emitted = ps.emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
-                            ps.ray_color = ps.ray_color * select3(is_refr, base, select3(is_spec, spec, base));
-                            ps.incoming = ps.incoming + ps.emitted * ps.ray_color;
-                            done = ps.bounces >= max_bounces;
-                            if (!done) {
-                                // the new direction (rt.comp:296-305) is finished in the direction phase; at the last
-                                // bounce the shader computes one too, but nothing reads it
-                                hp = ps.o + ps.d * h.t;                 // hitPoint (rt.comp:175 / :144)
-                                nrm = h.normal; eta = ior; refr = is_refr;
-                                mix_a = is_spec ? m->specularSmoothness : m_smooth; mix_b = m_smooth;
-                                state = S_DIR;
-                            }
-                        } else {
-                            ps.bounces++;
-                            ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);  // skyColor * skyIntensity (rt.comp:315)
-                            ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
-                        }
-                        const float nb = (float)ps.bounces;
-                        colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
-                    }
-                    if (done) {
-                        fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = make_float4(colour.x, colour.y, colour.z, 1.0f);
-                        k++;
-                        state = k < k_end ? S_FRESH : S_DEAD;
-                    }
-                }
-            }
-            PT_TICK(c2);
-            PT_ACC(cyc_shade, c1, c2);
-            // ---- direction phase: RandomDirection (rt.comp:85-90) once for both of its callers -- the jitter of a new
-            // primary ray (rt.comp:326-333) and the bounce direction of a continuing path (rt.comp:296-305)
-            if (__any(state == S_FRESH || state == S_DIR)) {
-                n_samples += __popcll(__ballot(state == S_FRESH));
-                if (state == S_FRESH || state == S_DIR) {
-                    const bool fresh = state == S_FRESH;
-                    if (fresh) ps.rng = (uint32_t)(fp.first_pass + k) * pix_seed;       // rt.comp:327
-                    const float gx = random_value_nd(ps.rng), gy = random_value_nd(ps.rng), gz = random_value_nd(ps.rng);
-                    const v3 g = V(gx, gy, gz);
-                    const float gr = exact_rcp(sqrtf(dot(g, g)));        // normalize(v) = v * (1/sqrt(dot(v,v)))
-                    if (fresh) {
-                        // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
-                        const v3 jit = (g * 0.00025f) * gr;
-                        const float X = -pix_x + jit.x, Y = pix_y + jit.y;
-                        const float *m = fp.iv;
-                        ps.d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
-                        ps.o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
-                        ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
-                    } else {
-                        const v3 r = g * gr;
-                        const v3 hemi = dot(r, nrm) > 0.0f ? r : -r;    // rt.comp:92-95
-                        const v3 a = mix3(hemi, reflect3(ps.d, nrm), mix_a);
-                        const v3 b = mix3(-hemi, refract3(ps.d, nrm, eta), mix_b);
-                        ps.d = normalize(select3(refr, b, a));
-                        ps.o = hp + ps.d * 0.0002f;                     // rt.comp:305
-                    }
-                    state = S_TRACE;
-                }
-            }
-            PT_TICK(c3);
-            PT_ACC(cyc_gen, c2, c3);
-            // ---- trace phase: root-AABB gate (rt.comp:213) and scene primitives (rt.comp:219-230); the mesh is deferred
-            if (__any(state == S_TRACE)) {
-                bool gate = false;
-                if (state == S_TRACE) {
-                    if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
-                    s_t = kInfinity; s_id = -1;
-                    scene_closest(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
-                }
-                n_seg += __popcll(__ballot(state == S_TRACE));
-                n_mesh_seg += __popcll(__ballot(gate));
-                n_prim_mesh_seg += __popcll(__ballot(gate && ps.bounces == 0));
-                if (state == S_TRACE) {
-                    state = S_READY;                                    // (s_t, s_id) is final unless the trees are needed
-                    if (gate || sph_root >= 0) {
-                        pool.res_id[tid] = kNotReady;                   // before the ray becomes visible
-                        const unsigned sa = atomicAdd(&pool.ctl[0], 1u), slot = sa & (kPoolCap - 1);
-                        pool.ray[0 * kPoolCap + slot] = ps.o.x; pool.ray[1 * kPoolCap + slot] = ps.o.y; pool.ray[2 * kPoolCap + slot] = ps.o.z;
-                        pool.ray[3 * kPoolCap + slot] = ps.d.x; pool.ray[4 * kPoolCap + slot] = ps.d.y; pool.ray[5 * kPoolCap + slot] = ps.d.z;
-                        const unsigned gen = ((sa / kPoolCap) + 1) & 0xffffu;
-                        __hip_atomic_store(&pool.tag[slot], gen << 16 | (gate ? 0x8000u : 0u) | (unsigned)tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        state = S_WAIT;
-                        waited = 0;
-                    }
-                }
-            }
-            PT_TICK(c4);
-            PT_ACC(cyc_trace, c3, c4);
-        }
-    }
-    if (fp.counters) {
-        for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); }
-        if (lane == 0) {
-            atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
-            atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
-            atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
-            atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
-            atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
-            atomicAdd(&fp.counters[6], (unsigned long long)n_prim_mesh_seg);
-            atomicAdd(&fp.counters[10], (unsigned long long)n_bvh_nodes);
-            atomicAdd(&fp.counters[11], (unsigned long long)n_bvh_tests);
-            if (PT_PHASE_TIMERS) { atomicAdd(&fp.counters[12], cyc_gen); atomicAdd(&fp.counters[13], cyc_trace); atomicAdd(&fp.counters[14], cyc_shade); atomicAdd(&fp.counters[15], cyc_mesh); }
-            const unsigned long long span = wall_clock64() - t_start;
-            atomicAdd(&fp.counters[7], 1ull);
-            atomicAdd(&fp.counters[8], span);
-            atomicMax(&fp.counters[9], span);
-        }
-    }
-}
-
 // VGPR-resident triangles: persistent single-wave workgroups, 3 waves/SIMD (any mesh size).
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
@@ -1560,37 +1149,6 @@ __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneV
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
     trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
-}
-
-// LDS-resident BVH + ray pool shared by the 16 waves of one 1,024-thread workgroup per CU (trace_items_body_pool).
-// Dynamic LDS = nodes | triangles | spheres | stacks (stack_entries x 4 B x 1024) | pool rays (24 KB) | tags (4 KB) |
-// mailboxes (8 KB) | ring counters.
-constexpr int kPoolBlock = 1024;
-template <bool SPH>
-__global__ void __launch_bounds__(kPoolBlock, 4) pt_trace_items_pool(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
-{
-    extern __shared__ float4 bvh_lds[];
-    const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh;
-    unsigned *stack = reinterpret_cast<unsigned *>(sph + n_sph_rec);
-    RayPool pool;
-    pool.ray = reinterpret_cast<float *>(stack + stack_entries * kPoolBlock);
-    pool.tag = reinterpret_cast<unsigned *>(pool.ray + 6 * kPoolCap);
-    pool.res_t = reinterpret_cast<float *>(pool.tag + kPoolCap);
-    pool.res_id = reinterpret_cast<int *>(pool.res_t + kPoolBlock);
-    pool.ctl = reinterpret_cast<unsigned *>(pool.res_id + kPoolBlock);
-    for (int i = threadIdx.x; i < 4 * n_nodes; i += kPoolBlock) nodes[i] = sc.bvh_nodes[i];
-    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kPoolBlock) tris[i] = sc.bvh_tris[i];
-    for (int i = threadIdx.x; i < n_sph_rec; i += kPoolBlock) sph[i] = sc.bvh_sph[i];
-    for (int i = threadIdx.x; i < kPoolCap; i += kPoolBlock) pool.tag[i] = 0u;
-    pool.res_id[threadIdx.x] = kNotReady;
-    if (threadIdx.x < 4) pool.ctl[threadIdx.x] = 0u;
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    BvhLdsStore st;
-    st.stack = stack + wave * (stack_entries * kWave) + lane;
-    st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
-    trace_items_body_pool<SPH>(sc, fp, st, pool, lane, (int)threadIdx.x);
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)

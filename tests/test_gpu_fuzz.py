@@ -1,4 +1,4 @@
-"""Randomised and adversarial scenes: the BVH traversal kernels (variants 5/6/7) against the brute-force kernel, which
+"""Randomised and adversarial scenes: the BVH traversal kernels (variants 5/6) against the brute-force kernel, which
 scans every primitive exactly like the reference shader, and against the CPU oracle.  The adversarial cases aim at the one
 situation the traversal does not cover by construction: rays (nearly) coplanar with mesh triangles."""
 import numpy as np
@@ -59,7 +59,7 @@ def test_random_scenes_all_variants_and_oracle(capi, seed):
     W, H, B, SPP = 96, 56, 6, 3
     ref, c_ref = render(capi, sc, cam, W, H, B, SPP, 1)
     assert c_ref["bvh_tri_tests"] == 0                 # variant 1 = brute force (some cameras look away from the mesh)
-    for variant in (5, 6, 7):
+    for variant in (5, 6):
         img, c = render(capi, sc, cam, W, H, B, SPP, variant)
         assert c["mesh_tri_tests"] == 0 and (c["bvh_tri_tests"] > 0 or c_ref["mesh_segments"] == 0), variant
         assert bits_equal(img, ref), (seed, variant, n_diff_pixels(img, ref))
@@ -119,7 +119,7 @@ def test_axis_parallel_rays_and_degenerate_triangles(capi):
     cam = S.Camera(position=np.array([0.25, 0.5, -2.0], np.float32), yaw=90.0, pitch=0.0).UpdateView()
     W, H, B, SPP = 128, 72, 4, 4
     ref, _ = render(capi, sc, cam, W, H, B, SPP, 1)
-    for variant in (5, 6, 7):
+    for variant in (5, 6):
         img, _ = render(capi, sc, cam, W, H, B, SPP, variant)
         assert bits_equal(img, ref), (variant, n_diff_pixels(img, ref))
     assert n_diff_pixels(ref, O.Oracle(sc, cam, W, H, B).render(1, SPP)) == 0
