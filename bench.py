@@ -48,20 +48,28 @@ def executed_flops(c, sc):
             + FLOP_SPHERE * c["segments"] * len(sc.spheres) + FLOP_AABB * c["segments"] + FLOP_SHADE * c["hits"])
 
 
-def cpu_baseline(sc, cam):
+def cpu_baseline(sc, cam, gpu_image=None):
     """The oracle (C restatement of the reference, oracle/pt_oracle.c) timed on this host's cores on a bounded
-    sample of the SAME workload: every 2nd row of the 1080p frame (540 rows x 1920 px), 64 spp, 8 bounces."""
+    sample of the SAME workload: every 2nd row of the 1080p frame (540 rows x 1920 px), 64 spp, 8 bounces.
+    The rows it renders are also compared, bit for bit, with the image the GPU produced in the timed steps."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     o = O.Oracle(sc, cam, W, H, BOUNCES)
     rows = list(range(1, H, 2))
     o.render_region(1, 1, 0, rows[0], W, 1)          # warm up (page in, thread pool)
     t0 = time.perf_counter()
+    got = []
     for y in rows:
-        o.render_region(1, SPP, 0, y, W, 1)
+        got.append(o.render_region(1, SPP, 0, y, W, 1)[0])
     dt = time.perf_counter() - t0
     n = len(rows) * W * SPP
-    return {"value": n / dt, "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
+    parity = None
+    if gpu_image is not None:
+        want = np.stack(got)                                             # (540, W, 4)
+        have = gpu_image[rows]
+        diff = (want.view(np.uint32) != have.view(np.uint32)).any(axis=-1)
+        parity = {"rows_checked": len(rows), "pixels_checked": int(diff.size), "pixels_differing_bitwise": int(diff.sum())}
+    return {"parity_vs_oracle": parity, "value": n / dt, "unit": "samples/s", "cores": O.num_threads(), "kind": "port",
             "sample": f"oracle/pt_oracle.c (OpenMP) on rows 1,3,..,{rows[-1]} of the 1920x1080 frame ({len(rows)} rows x {W} px), "
                       f"{SPP} spp, {BOUNCES} bounces = {n} samples in {dt:.1f} s"}
 
@@ -150,6 +158,7 @@ def main():
     achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
     kernel_name = {0: capi.load().pt_kernel_name().decode(), 1: "pt_trace_items", 5: "pt_trace_items_bvh", 6: "pt_trace_items_bvh_lds"}.get(a.variant, "pt_trace_items_lds")
 
+    final_image = accum.cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
     brute = None
     if rank == 0 and world == 1 and not a.no_brute_force and kernel_name.startswith("pt_trace_items_bvh"):
         # outside the timed region: the same render on the brute-force kernel (exact by construction), to show what the
@@ -198,7 +207,7 @@ def main():
         if brute:
             out["brute_force_kernel"] = brute
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc, cam)
+            out["cpu_baseline"] = cpu_baseline(sc, cam, final_image)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
