@@ -150,7 +150,7 @@ SceneView scene_view(const pt_ctx *c)
     s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
     s.mats = (const PtMaterial *)c->mats.p;
     s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
-    s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root; s.n_sph_nodes = (int)c->h_sph_nodes.size();
+    s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root;
     return s;
 }
 

@@ -1,17 +1,21 @@
 // pt_kernels.hpp — HIP kernels of the path-tracing hot path for gfx950 (MI355X, wave64).
 //
-// Structure ("triangle-stationary wave"): one wave64 owns 64 pixels of an image row for a few
-// passes (see pt_trace_items).  Pixel work (ray generation, RNG, shading, accumulation) runs one pixel per lane.  The
-// >99 % hot loop -- brute-force ray/triangle tests against the mesh (rt.comp:213-218) -- runs the
-// other way round: every lane keeps SLOTS mesh triangles in VGPRs for the whole kernel (loaded once,
-// coalesced, from a slot-major SoA image), and the rays that passed the root-AABB gate are taken one
-// at a time from the wave's ballot mask, broadcast to all lanes through SGPRs (v_readlane), tested
-// against 64*SLOTS triangles at once, and reduced with a DPP min + ballot.  Cost is proportional to the
-// number of rays that need the mesh, independent of how they are scattered over lanes, so the
-// divergence that a pixel-per-lane loop suffers after the first bounce does not exist here.
-// Closest-hit ties resolve to the lowest primitive index exactly like the shader's in-order strict
-// `<` scan: lane l holds triangles [l*SLOTS, (l+1)*SLOTS), so "lowest lane among equal t" is
-// "lowest index".
+// Two families of trace kernels, same work decomposition (persistent waves, work items = 64 px of a row x a range of
+// passes, pulled from an atomic queue in heaviest-first order), same per-sample arithmetic (pt_math.hpp):
+//
+//  * pt_trace_items_bvh_lds / pt_trace_items_bvh (default): every lane runs a small path state machine; rays that pass the
+//    root-AABB gate are parked and traversed together through a BVH (pt_bvh.hpp) that only SKIPS triangles -- the tests
+//    that remain are the reference's, the winner is the lexicographic minimum of (t, canonical id).  See the comment
+//    above trace_items_body_bvh.
+//
+//  * pt_trace_items_lds / pt_trace_items ("triangle-stationary waves", exact by construction): pixel work runs one pixel
+//    per lane, but the brute-force ray/triangle loop against the mesh (rt.comp:213-218) runs the other way round: every
+//    lane keeps SLOTS mesh triangles (in a workgroup-shared LDS image, or in VGPRs), and the rays that passed the gate are
+//    taken one at a time from the wave's ballot mask, broadcast to all lanes (v_readlane), tested against 64*SLOTS
+//    triangles at once, and reduced with a DPP min + ballot.  Cost is proportional to the number of rays that need the
+//    mesh, however they are scattered over lanes.  Ties resolve to the lowest primitive index exactly like the shader's
+//    in-order strict `<` scan: lane l holds triangles [l*SLOTS, (l+1)*SLOTS), so "lowest lane among equal t" is "lowest
+//    index".
 #pragma once
 #include "pt_math.hpp"
 #include "pt_bvh_format.hpp"
@@ -53,7 +57,6 @@ struct SceneView {
     float bvh_scale;          // largest |coordinate| of the mesh and the spheres (for the traversal's safety margin)
     const float4 *bvh_sph;    // sphere tree leaves, 2 x float4 per sphere in leaf order: (centre, radius), (bits(sphere index), -, -, -)
     int sph_root;             // node index of the sphere tree's root in bvh_nodes, -1: spheres are scanned one by one
-    int n_sph_nodes;
 };
 
 struct FrameParams {
@@ -62,7 +65,7 @@ struct FrameParams {
     float iv[9];              // inverseView columns 0,1,2 (xyz each); column 3 and row w are never read (rt.comp:333)
     int max_bounces, debug_normal;
     int first_pass, n_passes; // passes of this batch: first_pass .. first_pass + n_passes - 1
-    int chunk;                // passes per work item
+    int chunk;                // passes per work item of the mesh tiles (class 0)
     int traced_width, rows, x_blocks;   // (W/8)*8, (H/8)*8 (glDispatchCompute(W/8, H/8, 1)), ceil(traced_width/64)
     int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
     float *accum;             // RGBA32F, row 0 = bottom
