@@ -12,6 +12,10 @@ g*64+1 .. (g+1)*64 of the same image as a plain sum, the per-GPU RGBA32F buffers
 with ONE reduce per render, rank 0 scales by 1/(64*N).  Per-GPU work is fixed -> weak scaling.
 
 Prints one JSON line on rank 0 (see the repo contract).
+
+Rehearsal of the N > 1 path on a one-GPU box (not a measurement; both ranks time-slice cuda:0, gloo instead of RCCL):
+  PT_BENCH_REHEARSAL=1 GLOO_SOCKET_IFNAME=lo python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 \
+      --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1
 """
 from __future__ import annotations
 
@@ -100,9 +104,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: path_tracer_amd has no CPU path")
+    # rehearsal on a one-GPU box (not a measurement): PT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and swaps RCCL,
+    # which refuses two ranks on one device, for gloo -- the rest of the N > 1 path is the real one
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     sc, cam = S.default_scene(), S.bench_camera()
     r = capi.Renderer(W, H, device=local_rank)
@@ -184,7 +196,8 @@ def main():
         out = {
             "metric": "samples/sec (1080p, 8 bounces)", "value": total_samples / dt, "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU over gloo): not a measurement",
             "config": {"workload": "configs[1]: default res/meshes scene (bunny1 656 tris + 2 scene tris), 1920x1080, "
                                    f"{SPP} spp per GPU, {BOUNCES} bounces, camera (1.5,0.4,0) yaw 0 pitch 0",
                        "width": W, "height": H, "spp_per_gpu": SPP, "spp_total": SPP * world, "max_bounces": BOUNCES,
