@@ -117,6 +117,21 @@ void *pt_accum_device_ptr(pt_ctx *ctx);
  * state after the jitter draws.  Any output pointer may be NULL.  (CalculateRay, rt.comp:204-232) */
 int pt_read_primary_hits(pt_ctx *ctx, int pass, int32_t *ids, float *t, float *dirs, uint32_t *rng_states);
 
+/* --- multi-GPU sample split without Python (no reference counterpart; BASELINE.json north_star; SURVEY 8b last row).
+ * One process (or thread) per GPU, each with its own context holding the full scene.  RCCL (librccl.so, loaded with
+ * dlopen on first use: the library itself does not link against it) carries ONE reduce of the RGBA32F sum images onto
+ * rank 0 per render, over xGMI inside a node.  path_tracer_amd/distributed.py is the same thing over torch.distributed. */
+#define PT_GROUP_ID_BYTES 128
+/* rank 0 creates the id and hands it to the other ranks by any means (file, pipe, MPI) */
+int pt_group_unique_id(char id[PT_GROUP_ID_BYTES]);
+/* collective over all ranks; binds the communicator to the context's device */
+int pt_group_init(pt_ctx *ctx, const char id[PT_GROUP_ID_BYTES], int rank, int world);
+/* collective: rank r traces its contiguous share of passes first_pass .. first_pass+total_spp-1 as a plain sum
+ * (pt_render_sum semantics, accumulation image zeroed first), the sums meet on rank 0, rank 0 scales by 1/total_spp.
+ * Afterwards rank 0's image is the mean of all samples (alpha 1); the other ranks' images hold their partial sums. */
+int pt_group_render(pt_ctx *ctx, int first_pass, int total_spp);
+int pt_group_finalize(pt_ctx *ctx);
+
 /* --- measurement */
 int pt_get_counters(pt_ctx *ctx, PtCounters *out);
 int pt_reset_counters(pt_ctx *ctx);

@@ -21,7 +21,8 @@ SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
     "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
-    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_bvh_selftest", "pt_kernel_name",
+    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
+    "pt_kernel_name",
     "pt_version",
 ]
 
@@ -79,6 +80,10 @@ def load():
     L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
     L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32, i32]
     L.pt_bvh_selftest.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
+    L.pt_group_unique_id.argtypes = [C.c_char_p]
+    L.pt_group_init.argtypes = [vp, C.c_char_p, i32, i32]
+    L.pt_group_render.argtypes = [vp, i32, i32]
+    L.pt_group_finalize.argtypes = [vp]
     L.pt_kernel_name.restype = C.c_char_p
     L.pt_version.restype = i32
     _lib = L
@@ -187,6 +192,25 @@ class Renderer:
         ms, n = C.c_float(), C.c_int()
         self._ck(self.L.pt_last_render_ms(self.h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
+
+    # --- multi-GPU sample split over RCCL without torch (pt_group_*)
+    @staticmethod
+    def group_unique_id():
+        L = load()
+        buf = C.create_string_buffer(128)
+        rc = L.pt_group_unique_id(buf)
+        if rc:
+            raise PtError(rc, L.pt_last_error(None).decode())
+        return buf.raw
+
+    def group_init(self, uid, rank, world):
+        self._ck(self.L.pt_group_init(self.h, C.create_string_buffer(uid, 128), rank, world))
+
+    def group_render(self, first_pass, total_spp):
+        self._ck(self.L.pt_group_render(self.h, first_pass, total_spp))
+
+    def group_finalize(self):
+        self._ck(self.L.pt_group_finalize(self.h))
 
     def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0, waves_per_cu=0, variant=0):
         self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes, waves_per_cu, variant))

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 
 #pragma clang fp contract(off)
 
@@ -83,6 +84,8 @@ struct pt_ctx {
     bool have_mesh = false, have_scene = false, have_camera = false;
     uint32_t max_mat_mesh = 0, max_mat_scene = 0;   // largest material index referenced
 
+    void *group_comm = nullptr;         // ncclComm_t of pt_group_init
+    int group_rank = 0, group_world = 0;
     float cam[3] = {0, 0, 0}, iv[9] = {0};
     int max_bounces = 3;              // rt.comp:23
     int debug_normal = 0;
@@ -368,6 +371,7 @@ void pt_destroy(pt_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->group_comm) (void)pt_group_finalize(c);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
                       &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
@@ -685,6 +689,101 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
     }
     *ms = total;
     if (n_launches) *n_launches = c->n_timed;
+    return PT_OK;
+}
+
+// ---- RCCL, resolved at run time ------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    typedef struct { char internal[PT_GROUP_ID_BYTES]; } UniqueId;            // ncclUniqueId (rccl.h:43)
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { r.why = std::string("librccl.so not loadable: ") + dlerror(); return r; }
+    r.GetUniqueId = (int (*)(Rccl::UniqueId *))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void **, int, Rccl::UniqueId, int))dlsym(h, "ncclCommInitRank");
+    r.Reduce = (int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t))dlsym(h, "ncclReduce");
+    r.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+    r.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.Reduce && r.CommDestroy && r.GetErrorString;
+    if (!r.ok) r.why = "librccl.so lacks an expected symbol";
+    return r;
+}
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;                                   // rccl.h:448,466
+}  // namespace
+
+int pt_group_unique_id(char id[PT_GROUP_ID_BYTES])
+{
+    if (!id) return PT_E_INVALID;
+    Rccl &r = rccl();
+    if (!r.ok) return fail(nullptr, PT_E_STATE, "%s", r.why.c_str());
+    Rccl::UniqueId u;
+    const int rc = r.GetUniqueId(&u);
+    if (rc) return fail(nullptr, PT_E_HIP, "ncclGetUniqueId: %s", r.GetErrorString(rc));
+    std::memcpy(id, u.internal, PT_GROUP_ID_BYTES);
+    return PT_OK;
+}
+
+int pt_group_init(pt_ctx *c, const char id[PT_GROUP_ID_BYTES], int rank, int world)
+{
+    if (!c || !id) return PT_E_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, PT_E_INVALID, "bad rank %d / world %d", rank, world);
+    if (c->group_comm) return fail(c, PT_E_STATE, "the context already belongs to a group (pt_group_finalize first)");
+    Rccl &r = rccl();
+    if (!r.ok) return fail(c, PT_E_STATE, "%s", r.why.c_str());
+    Bind b(c); HIPCHK(c, b.e);
+    Rccl::UniqueId u;
+    std::memcpy(u.internal, id, PT_GROUP_ID_BYTES);
+    const int rc = r.CommInitRank(&c->group_comm, world, u, rank);
+    if (rc) { c->group_comm = nullptr; return fail(c, PT_E_HIP, "ncclCommInitRank: %s", r.GetErrorString(rc)); }
+    c->group_rank = rank; c->group_world = world;
+    return PT_OK;
+}
+
+int pt_group_render(pt_ctx *c, int first_pass, int total_spp)
+{
+    if (!c) return PT_E_INVALID;
+    if (!c->group_comm) return fail(c, PT_E_STATE, "pt_group_init first");
+    if (first_pass < 1 || total_spp < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, total_spp);
+    int rc = check_ready(c);
+    if (rc) return rc;
+    Bind b(c); HIPCHK(c, b.e);
+    // contiguous, balanced split (the first total % world ranks take one pass more): path_tracer_amd/distributed.py pass_range
+    const int base = total_spp / c->group_world, extra = total_spp % c->group_world;
+    const int count = base + (c->group_rank < extra ? 1 : 0);
+    const int first = first_pass + c->group_rank * base + std::min(c->group_rank, extra);
+    const size_t n_floats = (size_t)c->width * c->height * 4;
+    HIPCHK(c, hipMemsetAsync(c->accum, 0, n_floats * sizeof(float), c->stream));
+    if (count > 0 && (rc = launch_trace(c, first, count, 1)) != PT_OK) return rc;
+    Rccl &r = rccl();
+    const int nrc = r.Reduce(c->accum, c->accum, n_floats, kNcclFloat32, kNcclSum, 0, c->group_comm, c->stream);
+    if (nrc) return fail(c, PT_E_HIP, "ncclReduce: %s", r.GetErrorString(nrc));
+    if (c->group_rank == 0) return pt_scale_accum(c, 1.0f / (float)total_spp, 1);
+    return PT_OK;
+}
+
+int pt_group_finalize(pt_ctx *c)
+{
+    if (!c) return PT_E_INVALID;
+    if (!c->group_comm) return PT_OK;
+    Bind b(c); HIPCHK(c, b.e);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int rc = rccl().CommDestroy(c->group_comm);
+    c->group_comm = nullptr; c->group_world = 0; c->group_rank = 0;
+    if (rc) return fail(c, PT_E_HIP, "ncclCommDestroy: %s", rccl().GetErrorString(rc));
     return PT_OK;
 }
 

@@ -6,12 +6,16 @@
 //           [--orbit FRAMES DEGREES]   scripted stand-in for the interactive loop (src/Main.cpp:108-150): every frame the
 //                                      camera turns by DEGREES of yaw around the scene centre, which restarts the
 //                                      accumulation (currAccumPass = 0 + clear, src/Main.cpp:110-117), then --spp passes
+//           [--group RANK WORLD IDFILE] one process per GPU (give each its --device): the --spp passes are split over the
+//                                      WORLD ranks, one RCCL reduce brings the sums to rank 0, which writes the outputs
+//                                      (pt_group_*, include/pt_hip.h); IDFILE is a path all ranks can reach
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "Renderer.h"
@@ -46,6 +50,7 @@ int main(int argc, char **argv)
     bool debugNormal = false, batch = false, cam_given = false, print_camera = false;
     float cam[5] = {1.5f, 0.4f, 0.0f, 0.0f, 0.0f};
     int orbit_frames = 0; float orbit_deg = 0.0f;
+    int group_rank = 0, group_world = 0; std::string group_id_path;     // --group: one process per GPU, samples split over RCCL
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (!std::strcmp(argv[i], "--mesh")) mesh_path = next();
@@ -61,6 +66,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--batch")) batch = true;
         else if (!std::strcmp(argv[i], "--print-camera")) print_camera = true;
         else if (!std::strcmp(argv[i], "--orbit")) { orbit_frames = std::atoi(next()); orbit_deg = std::strtof(next(), nullptr); }
+        else if (!std::strcmp(argv[i], "--group")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); }
         else if (!std::strcmp(argv[i], "--cam")) { for (int k = 0; k < 5; k++) cam[k] = std::strtof(next(), nullptr); cam_given = true; }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -121,6 +127,30 @@ int main(int argc, char **argv)
         std::printf("Frames: %d x %d spp | %.3f ms per frame | %.1f frames/s | final camera %.9g %.9g %.9g yaw %.9g\n", orbit_frames, spp,
                     dt * 1e3 / orbit_frames, orbit_frames / dt, Renderer::camera.position.x, Renderer::camera.position.y,
                     Renderer::camera.position.z, Renderer::camera.yaw);
+    } else if (group_world > 0) {
+        // rank 0 makes the RCCL id and publishes it through a file (written aside, then renamed: never seen half-written)
+        char id[PT_GROUP_ID_BYTES];
+        if (group_rank == 0) {
+            if (!Renderer::Check(pt_group_unique_id(id), "pt_group_unique_id")) return 1;
+            const std::string tmp = group_id_path + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { std::perror(tmp.c_str()); return 1; }
+            std::fclose(f);
+            if (std::rename(tmp.c_str(), group_id_path.c_str())) { std::perror(group_id_path.c_str()); return 1; }
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 600 && !got; tries++) {        // up to 60 s for rank 0 to come up
+                FILE *f = std::fopen(group_id_path.c_str(), "rb");
+                if (f) { got = std::fread(id, 1, sizeof id, f) == sizeof id; std::fclose(f); }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            if (!got) { std::fprintf(stderr, "no group id in %s after 60 s\n", group_id_path.c_str()); return 1; }
+        }
+        if (!Renderer::Check(pt_group_init(Renderer::ctx, id, group_rank, group_world), "pt_group_init")) return 1;
+        if (!Renderer::Check(pt_group_render(Renderer::ctx, 1, spp), "pt_group_render")) return 1;
+        if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
+        if (!Renderer::Check(pt_group_finalize(Renderer::ctx), "pt_group_finalize")) return 1;
+        if (group_rank != 0) { Renderer::Shutdown(); return 0; }       // the finished image lives on rank 0
     } else if (batch) {
         if (!Renderer::Check(pt_render(Renderer::ctx, 1, spp), "pt_render")) return 1;
     } else {

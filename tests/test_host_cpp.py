@@ -83,3 +83,18 @@ def test_pt_main_scripted_camera_loop(tmp_path):
     ia, ib = np.fromfile(a, np.float32), np.fromfile(b, np.float32)
     assert ia.size == 320 * 184 * 4 and np.array_equal(ia.view(np.uint32), ib.view(np.uint32))
     assert float(ia.reshape(184, 320, 4)[:, :, :3].max()) > 0
+
+
+@pytest.mark.gpu
+def test_pt_main_group_of_one_matches_batch_within_tolerance(tmp_path):
+    """--group RANK WORLD IDFILE at world 1 (all a one-GPU box can hold): id file hand-over, pt_group_init/render/finalize;
+    sum/spp vs the running mean of --batch, same tolerance as test_sum_mode_matches_mean_within_tolerance"""
+    obj, a, b, idf = tmp_path / "bunny1.obj", tmp_path / "group.f32", tmp_path / "batch.f32", tmp_path / "rccl.id"
+    _write_obj(obj)
+    common = [PT_MAIN, "--mesh", str(obj), "--width", "320", "--height", "184", "--spp", "16", "--bounces", "4"]
+    subprocess.run(common + ["--group", "0", "1", str(idf), "--out", str(a)], check=True, capture_output=True, timeout=120)
+    subprocess.run(common + ["--batch", "--out", str(b)], check=True, capture_output=True, timeout=120)
+    assert os.path.getsize(idf) == 128
+    ia, ib = np.fromfile(a, np.float32).reshape(184, 320, 4), np.fromfile(b, np.float32).reshape(184, 320, 4)
+    assert np.all(ia[:, :, 3] == 1.0)
+    np.testing.assert_allclose(ia[:, :, :3], ib[:, :, :3], rtol=1e-5, atol=1e-6)
