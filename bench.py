@@ -78,6 +78,26 @@ def cpu_baseline(sc, cam, gpu_image=None):
                       f"{SPP} spp, {BOUNCES} bounces = {n} samples in {dt:.1f} s"}
 
 
+def profiled_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/<dir>/summary.json, tools/profile.sh: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE).  bench.py
+    cannot collect PMC counters itself; null when the newest profile is of another kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("kernel") != kernel_name:
+                break
+            dv = d["derived"]
+            rd = next(v for k, v in dv.items() if k.startswith("hbm_read_bytes_per_launch"))
+            wr = next(v for k, v in dv.items() if k.startswith("hbm_write_bytes_per_launch"))
+            return {"traffic": rd + wr, "traffic_unit": "bytes per launch (read %.3g + write %.3g)" % (rd, wr),
+                    "traffic_source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))}
+        except (OSError, ValueError, KeyError, StopIteration):
+            break
+    return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,7 +223,7 @@ def main():
                        "width": W, "height": H, "spp_per_gpu": SPP, "spp_total": SPP * world, "max_bounces": BOUNCES,
                        "parallelism": "spp-split x%d + 1 RCCL reduce/render" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_VALU_PEAK_TFLOPS, **profiled_traffic(kernel_name),
                          "kernel": kernel_name, "kernel_ms": k_ms,
                          "algorithmic_flop_per_launch": flops_per_launch,
                          # the same segments traced the reference's way (every mesh triangle behind the gate)
