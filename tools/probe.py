@@ -33,5 +33,6 @@ for i in range(a.reps + 1):
     r.reset(); r.reset_counters(); r.render(1, a.spp); ms.append(r.last_render_ms())
 c = r.counters()
 bal = c["wave_ticks_sum"] / max(1, c["waves"] * c["wave_ticks_max"])
-print(json.dumps({"args": vars(a), "kernel_ms": [round(m, 3) for m in ms[1:]], "balance": round(bal, 3),
-                  "span_max_ms": c["wave_ticks_max"] / 1e5, **{k: c[k] for k in ("samples", "segments", "mesh_segments", "hits", "wave_iterations", "bvh_node_visits", "bvh_tri_tests", "phase_cycles")}}))
+import zlib
+print(json.dumps({"crc": zlib.crc32(r.read_accum().tobytes()), "args": vars(a), "kernel_ms": [round(m, 3) for m in ms[1:]], "balance": round(bal, 3),
+                  "span_max_ms": c["wave_ticks_max"] / 1e5, **{k: c[k] for k in ("samples", "segments", "mesh_segments", "hits", "wave_iterations", "bvh_node_visits", "bvh_tri_tests", "mesh_tri_tests", "phase_cycles")}}))
