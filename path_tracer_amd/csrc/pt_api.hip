@@ -182,15 +182,6 @@ size_t bvh_lds_bytes(const pt_ctx *c)
     return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)(c->bvh_depth + 1) * 4 * kBvhLdsBlock;
 }
 
-// Variant 7 (specialised waves): stacks only for the n_v traversal waves, + mailboxes (8 x 8 x 64 dwords) + flags.
-int split_nv() { static const int nv = getenv("PT_SPLIT_NV") ? std::max(1, std::min(4, atoi(getenv("PT_SPLIT_NV")))) : 2; return nv; }
-int split_waves() { static const int nw = getenv("PT_SPLIT_WAVES") ? std::max(split_nv() + 1, std::min(kSplitBlockMax / kWave, atoi(getenv("PT_SPLIT_WAVES")))) : kSplitBlockMax / kWave; return nw; }
-size_t bvh_split_lds_bytes(const pt_ctx *c, int n_v)
-{
-    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)(c->bvh_depth + 1) * 4 * kWave * n_v
-           + (size_t)split_waves() * 8 * kWave * 4 + 33 * 8;
-}
-
 // Concatenate the two trees' nodes (mesh first: its root is node 0; the sphere tree's child indices are shifted) and upload.
 int sync_bvh(pt_ctx *c)
 {
@@ -226,7 +217,6 @@ int pick_variant(const pt_ctx *c)
 {
     int variant = c->variant ? c->variant : PT_DEFAULT_VARIANT;
     if (variant >= 5 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
-    if (variant == 7 && (bvh_split_lds_bytes(c, split_nv()) > kBvhLdsLimit)) variant = 6;
     if (variant == 6 && bvh_lds_bytes(c) > kBvhLdsLimit) variant = 5;     // too large for two workgroups per CU
     if (variant >= 2 && variant <= 4 && c->n_chunks != 1) variant = 1;    // the LDS image holds exactly one chunk
     return variant;
@@ -246,7 +236,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     // becomes the tail of the launch (measured on config 2: 10.6 ms fused vs 7.8 ms with 4-pass items).
     const bool allow_fused = !(getenv("PT_NO_FUSED") && atoi(getenv("PT_NO_FUSED")));   // read per call: tests flip it
     const int variant0 = pick_variant(c);
-    const bool fused = allow_fused && (variant0 == 5 || variant0 == 6 || variant0 == 7) && n_passes <= c->chunk_passes;
+    const bool fused = allow_fused && (variant0 == 5 || variant0 == 6) && n_passes <= c->chunk_passes;
     const int batch = fused ? n_passes : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, c->workspace_limit / plane_bytes));
     if (!fused && c->radiance.bytes < plane_bytes * batch) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -292,8 +282,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
             HIPCHK(c, hipGetLastError());
             c->order_dirty = false;
         }
-        int variant = pick_variant(c);
-        if (variant == 7 && fused) variant = 6;                               // short launches keep the unsplit kernel
+        const int variant = pick_variant(c);
         HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(unsigned), c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
         if (variant == 1) {
@@ -305,17 +294,6 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         } else if (variant == 3) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 5);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
-        } else if (variant == 7) {
-            int n_v = split_nv();
-            const int n_s = split_waves() - n_v;
-            const unsigned grid = (unsigned)std::min<long long>((items + n_s - 1) / n_s, (long long)c->n_cus * 2);
-            const size_t lds = bvh_split_lds_bytes(c, n_v);
-            const void *kern = c->sph_root >= 0 ? (const void *)&pt_trace_items_bvh_split<true> : (const void *)&pt_trace_items_bvh_split<false>;
-            HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            static const int refill = getenv("PT_SPLIT_REFILL") ? atoi(getenv("PT_SPLIT_REFILL")) : 16, steps = getenv("PT_SPLIT_STEPS") ? atoi(getenv("PT_SPLIT_STEPS")) : 4;
-            int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + 1, refill_min = std::max(1, std::min(64, refill)), steps_per_round = std::max(1, steps);
-            void *args[] = {&sv, &fp, &n_nodes, &entries, &n_v, &refill_min, &steps_per_round};
-            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(split_waves() * kWave), args, lds, c->stream));
         } else if (variant == 6) {
             const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
             const size_t lds = bvh_lds_bytes(c);
@@ -869,7 +847,7 @@ int pt_bvh_selftest(const PtTriangle *tris, int n, int *n_nodes, int *depth, int
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;
-    if (variant < 0 || variant > 7) return fail(c, PT_E_INVALID, "variant outside [0,7]");
+    if (variant < 0 || variant > 6) return fail(c, PT_E_INVALID, "variant outside [0,6]");
     if (variant) c->variant = variant;
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
     if (waves_per_cu) c->waves_per_cu = waves_per_cu;

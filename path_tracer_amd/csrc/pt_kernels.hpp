@@ -664,26 +664,8 @@ enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DI
 // SPH: the scene has a sphere tree (compile-time, so scenes without spheres carry none of its code or registers).
 // SHORT: launches of a few passes (interactive use): items are dealt round-robin to the waves instead of pulled from the
 // queue, every item covers all passes, and the lane keeps the running mean in registers (no workspace, no pt_accumulate).
-constexpr int kBvhLdsBlock = 512;         // threads per workgroup of the LDS-resident BVH kernels
-// SPLIT (variant 7): the waves of a workgroup are specialised.  Path waves run this body but never traverse: a ray that
-// needs the trees is posted to the lane's mailbox in LDS and the lane waits in S_MESH until a traversal wave
-// (traverse_server below) has answered.  Mailbox layout: [wave][8 dwords][64 lanes] = origin, direction, (gate flag | t), id.
-struct SplitCtx {
-    unsigned long long *pending;   // LDS [16]: per path wave, lanes whose request no traversal wave has claimed yet
-    unsigned long long *done;      // LDS [16]: per path wave, lanes whose answer is in the mailbox
-    unsigned *s_alive;             // LDS: path waves still running
-    float *mail;                   // LDS [n_waves][8][64]
-    int wave, n_v, n_waves;        // this wave's index in the workgroup; waves 0 .. n_v-1 are traversal waves
-};
-__device__ __forceinline__ float *mail_slot(const SplitCtx &sx, int wave, int j, int lane) { return sx.mail + ((wave * 8 + j) * kWave + lane); }
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
-{
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-constexpr unsigned long long kSplitWatchdogTicks = 300000000ull;   // 3 s of the 100 MHz wall clock: a lost request must not hang the GPU
-
-template <bool SPH, bool SHORT, class Store, bool SPLIT = false>
-__device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const FrameParams &fp, Store &st, int lane, const SplitCtx *sx = nullptr)
+template <bool SPH, bool SHORT, class Store>
+__device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
 {
     const int sph_root = SPH ? sc.sph_root : -1;
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
@@ -728,7 +710,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     v3 inv = V(0, 0, 0);
     float delta = 0.0f;
     int wait = 0;
-    unsigned long long idle_since = 0;                                      // SPLIT: wall clock when the wave began to wait idly
     {
         for (;;) {
             // ---- refill dead lanes with the next pixels
@@ -783,39 +764,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             n_iter++;
             const int n_mesh = __popcll(m_mesh), n_other = __popcll(m_other);
             PT_TICK(c0);
-            if (SPLIT) {
-                // ---- collect the answers of the traversal waves
-                if (n_mesh) {
-                    const unsigned long long d = uniform64(__hip_atomic_load(&sx->done[sx->wave], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    if (d) {
-                        idle_since = 0; wait = 0;
-                        if (state == S_MESH && ((d >> lane) & 1ull)) {
-                            best_t = *mail_slot(*sx, sx->wave, 6, lane);
-                            best_id = __float_as_int(*mail_slot(*sx, sx->wave, 7, lane));
-                            if (s_id >= 0 && (s_t < best_t || (s_t == best_t && s_id < best_id))) { best_t = s_t; best_id = s_id; }
-                            state = S_READY;
-                        }
-                        if (lane == 0) __hip_atomic_fetch_and(&sx->done[sx->wave], ~d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else if (n_other >= fp.park_high || wait >= fp.park_wait) {
-                        idle_since = 0; wait = 0;
-                    } else if (n_other > 0) {
-                        // few lanes have anything to do: give the traversal waves the issue slots for a moment
-                        wait++;
-                        __builtin_amdgcn_s_sleep(4);
-                        continue;
-                    } else {
-                        // every live lane waits for a traversal wave
-                        __builtin_amdgcn_s_sleep(4);
-                        const unsigned long long now = wall_clock64();
-                        if (!idle_since) idle_since = now;
-                        else if (now - idle_since > kSplitWatchdogTicks) {          // never observed: give up instead of hanging
-                            if (lane == 0 && fp.counters) atomicAdd(&fp.counters[3], 1ull);
-                            state = S_DEAD; more = false;
-                        }
-                        continue;
-                    }
-                }
-            } else if (n_mesh && (n_mesh >= fp.park_high || n_other == 0 || wait >= fp.park_wait)) {
+            if (n_mesh && (n_mesh >= fp.park_high || n_other == 0 || wait >= fp.park_wait)) {
                 // ---- traversal phase
                 wait = 0;
                 PT_COUNT(cyc_gen, 1); PT_COUNT(cyc_mesh, n_mesh);
@@ -1018,7 +967,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             PT_ACC(cyc_gen, c2, c3);
             // ---- trace phase: root-AABB gate (rt.comp:213) and scene primitives (rt.comp:219-230); the mesh is deferred
             if (__any(state == S_TRACE)) {
-                bool gate = false, posted = false;
+                bool gate = false;
                 if (state == S_TRACE) {
                     if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
                     s_t = kInfinity; s_id = -1;
@@ -1031,29 +980,15 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     if (gate || sph_root >= 0) {
                         // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
                         state = S_MESH;
-                        if (SPLIT) {
-                            posted = true;
-                            *mail_slot(*sx, sx->wave, 0, lane) = ps.o.x; *mail_slot(*sx, sx->wave, 1, lane) = ps.o.y; *mail_slot(*sx, sx->wave, 2, lane) = ps.o.z;
-                            *mail_slot(*sx, sx->wave, 3, lane) = ps.d.x; *mail_slot(*sx, sx->wave, 4, lane) = ps.d.y; *mail_slot(*sx, sx->wave, 5, lane) = ps.d.z;
-                            *mail_slot(*sx, sx->wave, 6, lane) = __int_as_float(gate ? 1 : 0);
-                        } else {
-                            sp = 0; best_t = kInfinity; best_id = -1;
-                            cur = gate ? 0 : sph_root;
-                            if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
-                            // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
-                            inv = V(__builtin_amdgcn_rcpf(ps.d.x), __builtin_amdgcn_rcpf(ps.d.y), __builtin_amdgcn_rcpf(ps.d.z));
-                            delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
-                        }
+                        sp = 0; best_t = kInfinity; best_id = -1;
+                        cur = gate ? 0 : sph_root;
+                        if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
+                        // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
+                        inv = V(__builtin_amdgcn_rcpf(ps.d.x), __builtin_amdgcn_rcpf(ps.d.y), __builtin_amdgcn_rcpf(ps.d.z));
+                        delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
                     } else {
                         state = S_READY;
                         best_t = s_t; best_id = s_id;
-                    }
-                }
-                if (SPLIT) {
-                    const unsigned long long req = __ballot(posted);
-                    if (req) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the mailbox writes of all lanes before the flag
-                        if (lane == 0) __hip_atomic_fetch_or(&sx->pending[sx->wave], req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -1061,7 +996,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             PT_ACC(cyc_trace, c3, c4);
         }
     }
-    if (SPLIT && lane == 0) __hip_atomic_fetch_sub(sx->s_alive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (fp.counters) {
         for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); }
         if (lane == 0) {
@@ -1078,178 +1012,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             atomicAdd(&fp.counters[7], 1ull);
             atomicAdd(&fp.counters[8], span);
             atomicMax(&fp.counters[9], span);
-        }
-    }
-}
-
-// Traversal wave of the SPLIT kernel: every lane holds one ray taken from the mailboxes of the workgroup's path waves, and
-// a lane whose ray is finished takes the next request at once, so the wave traverses with most lanes busy whatever the
-// rays' lengths.  Same node / leaf steps, margins and (t, id) rule as the traversal phase of trace_items_body_bvh.
-template <bool SPH, class Store>
-__device__ __forceinline__ void traverse_server(const SceneView &sc, const FrameParams &fp, Store &st, int lane, const SplitCtx &sx, int refill_min, int steps_per_round)
-{
-    const int sph_root = SPH ? sc.sph_root : -1;
-    const int n_s = sx.n_waves - sx.n_v;
-    unsigned *stk = st.stack;
-    unsigned n_bvh_nodes = 0, n_bvh_tests = 0;
-    bool active = false;
-    int my_wave = 0, my_lane = 0;
-    v3 o = V(0, 0, 0), d = V(0, 0, 0), inv = V(0, 0, 0), nlo = V(0, 0, 0), nhi = V(0, 0, 0);
-    float delta = 0.0f, best_t = kInfinity;
-    int best_id = -1, cur = 0, sp = 0, tri_pos = 0, tri_end = 0;
-    bool leaf_sph = false;
-    int rot = sx.wave;                                  // the traversal waves start their scans at different path waves
-    if (fp.park_exit == 1) __builtin_amdgcn_s_setprio(1); else if (fp.park_exit == 2) __builtin_amdgcn_s_setprio(2); else if (fp.park_exit == 3) __builtin_amdgcn_s_setprio(3);
-    for (;;) {
-        unsigned long long free_m = __ballot(!active);
-        int n_free = __popcll(free_m);
-        if (n_free >= refill_min) {
-            // one LDS round trip for all the request masks
-            const unsigned long long my_p = lane < sx.n_waves ? __hip_atomic_load(&sx.pending[lane & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-            const unsigned has = (unsigned)__ballot(my_p != 0ull);
-            for (int j = 0; j < n_s && n_free > 0 && has; j++) {
-                const int w = sx.n_v + (rot + j) % n_s;
-                if (!((has >> w) & 1u)) continue;
-                const unsigned long long p = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_p >> 32), w) << 32) | (unsigned)__builtin_amdgcn_readlane((int)my_p, w);
-                if (!p) continue;
-                // claim the lowest n_free requests of this path wave (another traversal wave may take some of them first)
-                const int r = __builtin_amdgcn_mbcnt_hi((unsigned)(p >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)p, 0));
-                const unsigned long long take = __ballot(((p >> lane) & 1ull) && r < n_free);
-                unsigned long long old = 0;
-                if (lane == 0) old = __hip_atomic_fetch_and(&sx.pending[w], ~take, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned long long got = uniform64(old) & take;
-                const int n_got = __popcll(got);
-                if (!n_got) continue;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // k-th free lane <- k-th claimed request: compact the claimed lane numbers to lanes 0.., then pull by rank
-                const int rg = __builtin_amdgcn_mbcnt_hi((unsigned)(got >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)got, 0));
-                const bool in = (got >> lane) & 1ull;
-                const int dst = in ? rg : n_got + (lane - rg);                      // a permutation of 0..63
-                const int compact = __builtin_amdgcn_ds_permute(dst << 2, lane);
-                const int rf = __builtin_amdgcn_mbcnt_hi((unsigned)(free_m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)free_m, 0));
-                const int src = __builtin_amdgcn_ds_bpermute(rf << 2, compact);
-                if (!active && rf < n_got) {
-                    o = V(*mail_slot(sx, w, 0, src), *mail_slot(sx, w, 1, src), *mail_slot(sx, w, 2, src));
-                    d = V(*mail_slot(sx, w, 3, src), *mail_slot(sx, w, 4, src), *mail_slot(sx, w, 5, src));
-                    const bool gate = __float_as_int(*mail_slot(sx, w, 6, src)) != 0;
-                    my_wave = w; my_lane = src; active = true;
-                    sp = 0; best_t = kInfinity; best_id = -1;
-                    cur = gate ? 0 : sph_root;
-                    if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
-                    inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-                    delta = 4e-6f * ((fabsf(o.x) + fabsf(o.y)) + (fabsf(o.z) + sc.bvh_scale));
-                    nlo = V(-((o.x + delta) * inv.x), -((o.y + delta) * inv.y), -((o.z + delta) * inv.z));
-                    nhi = V(-((o.x - delta) * inv.x), -((o.y - delta) * inv.y), -((o.z - delta) * inv.z));
-                }
-                free_m = __ballot(!active); n_free = __popcll(free_m);
-            }
-            rot++;
-            if (n_free == kWave) {
-                // nothing to do: leave once every path wave has left (a path wave leaves only when none of its lanes waits)
-                if (uniform64(__hip_atomic_load(sx.s_alive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) break;
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-        }
-        for (int step = 0; step < steps_per_round; step++) {
-            const int n = __popcll(__ballot(active));
-            if (!n) break;
-            const int n_node = __popcll(__ballot(active && cur >= 0));
-            int next = 0;
-            bool moved = false, fin = false;
-            if (2 * n_node >= n) {
-                if (active && cur >= 0) {
-                    float4 a, b, c;
-                    int kl, kr;
-                    st.node(cur, a, b, c, kl, kr);
-                    n_bvh_nodes++;
-                    float l0, l1, r0, r1;
-                    slab_test_fma(a.x, a.y, a.z, a.w, b.x, b.y, nlo, nhi, inv, l0, l1);
-                    slab_test_fma(b.z, b.w, c.x, c.y, c.z, c.w, nlo, nhi, inv, r0, r1);
-                    const float lim = fmaf(best_t, 1.001f, delta);
-                    const bool hl = l0 <= l1 && l1 >= -1e-4f && l0 <= lim, hr = r0 <= r1 && r1 >= -1e-4f && r0 <= lim;
-                    moved = true;
-                    if (hl && hr) {
-                        const bool left_first = l0 <= r0;
-                        next = left_first ? kl : kr;
-                        stk[sp * kWave] = (unsigned)(left_first ? kr : kl);
-                        sp++;
-                    } else if (hl) {
-                        next = kl;
-                    } else if (hr) {
-                        next = kr;
-                    } else if (sp == 0) {
-                        fin = true;
-                    } else {
-                        sp--;
-                        next = (int)stk[sp * kWave];
-                    }
-                }
-            } else {
-                if (SPH && active && cur < 0 && leaf_sph) {
-                    float4 cr;
-                    int si;
-                    st.sphere(tri_pos, cr, si);
-                    float t; bool front;
-                    const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, o, d, t, front);
-                    const int id = sc.n_mesh + sc.n_tris + si;
-                    n_bvh_tests++;
-                    if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                    tri_pos++;
-                    if (tri_pos == tri_end) {
-                        moved = true;
-                        if (sp == 0) fin = true;
-                        else { sp--; next = (int)stk[sp * kWave]; }
-                    }
-                } else if (active && cur < 0) {
-                    const bool two = tri_pos + 1 < tri_end;
-                    float4 p1, e1, e2, q1, f1, f2;
-                    st.tri(tri_pos, p1, e1, e2);
-                    st.tri(two ? tri_pos + 1 : tri_pos, q1, f1, f2);
-                    float t, det, t2, det2;
-                    bool bad = false;
-                    bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, bad);
-                    bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), o, d, t2, det2, bad);
-                    if (__builtin_expect(bad, 0)) {
-                        has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
-                        has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), o, d, t2, det2);
-                    }
-                    const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
-                    n_bvh_tests += two ? 2 : 1;
-                    if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                    if (two && has2 && (t2 < best_t || (t2 == best_t && id2 < best_id))) { best_t = t2; best_id = id2; }
-                    tri_pos += two ? 2 : 1;
-                    if (tri_pos == tri_end) {
-                        moved = true;
-                        if (sp == 0) fin = true;
-                        else { sp--; next = (int)stk[sp * kWave]; }
-                    }
-                }
-            }
-            if (moved) {
-                if (fin) {
-                    // answer: (t, id) over the trees; the path lane merges the scene primitives it scanned itself
-                    *mail_slot(sx, my_wave, 6, my_lane) = best_t;
-                    *mail_slot(sx, my_wave, 7, my_lane) = __int_as_float(best_id);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __hip_atomic_fetch_or(&sx.done[my_wave], 1ull << my_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    active = false;
-                } else if (next >= 0) {
-                    cur = next;
-                } else {
-                    const int code = ~next;
-                    leaf_sph = SPH && (code & kSphereLeaf) != 0;
-                    tri_pos = (code & (kSphereLeaf - 1)) >> 3; tri_end = tri_pos + (code & 7) + 1;
-                    cur = -1;
-                }
-            }
-        }
-    }
-    if (fp.counters) {
-        for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); }
-        if (lane == 0) {
-            atomicAdd(&fp.counters[10], (unsigned long long)n_bvh_nodes);
-            atomicAdd(&fp.counters[11], (unsigned long long)n_bvh_tests);
         }
     }
 }
@@ -1373,6 +1135,7 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
 // LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | stacks (stack_entries x 4 B x 512 lanes).
+constexpr int kBvhLdsBlock = 512;
 template <bool SPH, bool SHORT>
 __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
 {
@@ -1389,36 +1152,6 @@ __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneV
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
     trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
-}
-
-// Variant 7: the LDS-resident BVH with specialised waves: n_v traversal waves serve the rays of the other waves of the
-// workgroup (the path waves).  Workgroups of up to 10 waves, two per CU = 5 waves per SIMD (hence at most 102 VGPRs).
-// Dynamic LDS = nodes | triangles | spheres | stacks of the traversal waves | mailboxes (2 KB per wave) | flags.
-constexpr int kSplitBlockMax = 640;
-template <bool SPH>
-__global__ void __launch_bounds__(kSplitBlockMax, 5) pt_trace_items_bvh_split(SceneView sc, FrameParams fp, int n_nodes, int stack_entries, int n_v, int refill_min, int steps_per_round)
-{
-    extern __shared__ float4 bvh_lds[];
-    const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    const int n_waves = (int)blockDim.x / kWave;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh;
-    unsigned *stack = reinterpret_cast<unsigned *>(sph + n_sph_rec);
-    float *mail = reinterpret_cast<float *>(stack + n_v * (stack_entries * kWave));
-    unsigned long long *flags = reinterpret_cast<unsigned long long *>(mail + n_waves * 8 * kWave);
-    for (int i = threadIdx.x; i < 4 * n_nodes; i += blockDim.x) nodes[i] = sc.bvh_nodes[i];
-    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += blockDim.x) tris[i] = sc.bvh_tris[i];
-    for (int i = threadIdx.x; i < n_sph_rec; i += blockDim.x) sph[i] = sc.bvh_sph[i];
-    if (threadIdx.x < 32) flags[threadIdx.x] = 0ull;
-    if (threadIdx.x == 32) *reinterpret_cast<unsigned *>(flags + 32) = (unsigned)(n_waves - n_v);
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    SplitCtx sx;
-    sx.pending = flags; sx.done = flags + 16; sx.s_alive = reinterpret_cast<unsigned *>(flags + 32); sx.mail = mail; sx.wave = wave; sx.n_v = n_v; sx.n_waves = n_waves;
-    BvhLdsStore st;
-    st.stack = stack + (wave < n_v ? wave : 0) * (stack_entries * kWave) + lane;       // path waves never touch a stack
-    st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
-    if (wave < n_v) traverse_server<SPH>(sc, fp, st, lane, sx, refill_min, steps_per_round);
-    else trace_items_body_bvh<SPH, false, BvhLdsStore, true>(sc, fp, st, lane, &sx);
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
