@@ -6,6 +6,7 @@
 //           [--orbit FRAMES DEGREES]   scripted stand-in for the interactive loop (src/Main.cpp:108-150): every frame the
 //                                      camera turns by DEGREES of yaw around the scene centre, which restarts the
 //                                      accumulation (currAccumPass = 0 + clear, src/Main.cpp:110-117), then --spp passes
+//           [--add-mesh PATH MATERIAL]  (repeatable) further OBJ files, merged with --mesh into one traced mesh
 //           [--group RANK WORLD IDFILE] one process per GPU (give each its --device): the --spp passes are split over the
 //                                      WORLD ranks, one RCCL reduce brings the sums to rank 0, which writes the outputs
 //                                      (pt_group_*, include/pt_hip.h); IDFILE is a path all ranks can reach
@@ -14,8 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "Renderer.h"
@@ -50,6 +53,7 @@ int main(int argc, char **argv)
     bool debugNormal = false, batch = false, cam_given = false, print_camera = false;
     float cam[5] = {1.5f, 0.4f, 0.0f, 0.0f, 0.0f};
     int orbit_frames = 0; float orbit_deg = 0.0f;
+    std::vector<std::pair<std::string, int>> more_meshes;               // --add-mesh PATH MATERIAL (repeatable)
     int group_rank = 0, group_world = 0; std::string group_id_path;     // --group: one process per GPU, samples split over RCCL
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
@@ -66,6 +70,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--batch")) batch = true;
         else if (!std::strcmp(argv[i], "--print-camera")) print_camera = true;
         else if (!std::strcmp(argv[i], "--orbit")) { orbit_frames = std::atoi(next()); orbit_deg = std::strtof(next(), nullptr); }
+        else if (!std::strcmp(argv[i], "--add-mesh")) { const char *p = next(); more_meshes.emplace_back(p, std::atoi(next())); }
         else if (!std::strcmp(argv[i], "--group")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); }
         else if (!std::strcmp(argv[i], "--cam")) { for (int k = 0; k < 5; k++) cam[k] = std::strtof(next(), nullptr); cam_given = true; }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -87,6 +92,19 @@ int main(int argc, char **argv)
     default_materials(Renderer::scene);
     Mesh mesh(mesh_path.c_str(), mixed ? 1 : 3);
     if (!mesh.ok()) return 1;
+    // further meshes: traced together with the first as one merged mesh (the reference would keep only the last one)
+    std::vector<std::unique_ptr<Mesh>> extra;
+    std::unique_ptr<Mesh> merged;
+    if (!more_meshes.empty()) {
+        std::vector<const Mesh *> parts{&mesh};
+        for (const auto &mm : more_meshes) {
+            extra.emplace_back(new Mesh(mm.first.c_str(), (uint32_t)mm.second));
+            if (!extra.back()->ok()) return 1;
+            parts.push_back(extra.back().get());
+        }
+        merged.reset(new Mesh(parts));
+        if (!merged->ok()) return 1;
+    }
     Triangle(Renderer::scene, vec3(-1.0, 0.0, 3.0), vec3(1.0, 0.0, 3.0), vec3(0.0, 1.4, 3.0), 4);
     Triangle(Renderer::scene, vec3(5000.0, 0.0, 5000.0), vec3(-5000.0, 0.0, 5000.0), vec3(0.0, 0.0, -5000.0), 3);
     if (mixed) {    // the sphere grid main() carries commented out

@@ -58,6 +58,19 @@ Mesh::Mesh(std::vector<Triangle> triangles, uint32_t matIndex) : tris(std::move(
     Upload();
 }
 
+Mesh::Mesh(const std::vector<const Mesh *> &parts)
+{
+    loaded = !parts.empty();
+    for (const Mesh *m : parts) {
+        loaded = loaded && m->ok();
+        tris.insert(tris.end(), m->tris.begin(), m->tris.end());
+    }
+    if (!parts.empty()) materialIndex = parts[0]->materialIndex;
+    if (!loaded) { tris.clear(); return; }
+    GenBoundingBox();
+    Upload();
+}
+
 void Mesh::Load(const char *filePath)
 {
     std::ifstream in(filePath);

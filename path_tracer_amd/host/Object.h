@@ -80,6 +80,10 @@ struct Mesh {
 
     Mesh(const char *filePath, uint32_t materialIndex);                     // load OBJ + root AABB + upload (src/Object.cpp:89-111)
     Mesh(std::vector<Triangle> triangles, uint32_t materialIndex);          // same from triangles already in memory
+    // Several meshes as one (the reference's constructors rebind SSBO 1/2, so it only ever traces the mesh built last,
+    // src/Object.cpp:104-110): triangles concatenated in the order given, each with its own materialIndex, one root
+    // AABB over all of them.  Uploads the merged mesh.
+    explicit Mesh(const std::vector<const Mesh *> &parts);
     bool ok() const { return loaded; }
 private:
     bool loaded = false;

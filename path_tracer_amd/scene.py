@@ -96,6 +96,16 @@ class Mesh:
         return Mesh.from_arrays(v, fidx, materialIndex)
 
     @staticmethod
+    def merged(parts) -> "Mesh":
+        """Several meshes as ONE mesh for SSBO 1/2: in the reference every `Mesh` constructor rebinds
+        the two buffers, so only the mesh built last is traced (src/Object.cpp:104-110).  Here the triangles are
+        concatenated in the order given, each keeping its own materialIndex, behind one root AABB over all of them --
+        for the shader that is simply a bigger mesh (rt.comp:213-218), so the oracle and the kernels need nothing new."""
+        parts = list(parts)
+        tris = np.concatenate([m.tris for m in parts]) if parts else np.zeros(0, TRIANGLE_DTYPE)
+        return Mesh(tris, Mesh.gen_bounding_box(tris), parts[0].materialIndex if parts else 0)
+
+    @staticmethod
     def gen_bounding_box(tris: np.ndarray) -> np.ndarray:
         node = np.zeros(1, NODE_DTYPE)
         if len(tris):

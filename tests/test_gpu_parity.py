@@ -423,3 +423,35 @@ def test_fused_accumulation_equals_workspace_path(capi, cameras, scenes, monkeyp
         r.close()
     assert bits_equal(imgs["0"][0], imgs["1"][0]) and bits_equal(imgs["0"][1], imgs["1"][1])
     assert np.all(imgs["0"][1][:, :, 3] == 6.0)
+
+
+def _octahedron(centre, radius, material):
+    from path_tracer_amd import scene as S
+    c = np.asarray(centre, np.float32)
+    v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32) * np.float32(radius) + c
+    f = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.int32)
+    return S.Mesh.from_arrays(v, f, material), v, f
+
+
+@pytest.mark.parametrize("variant", [1, 6])
+def test_merged_meshes_with_their_own_materials_vs_oracle(capi, cameras, variant):
+    """several meshes traced as one (the reference keeps only the mesh built last): bunny (ground material)
+    + a mirror-like octahedron (material 0) + a glass one (material 2), per-triangle materials, one root AABB"""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    parts = [S.bunny_mesh(3), _octahedron((0.3, 0.35, 0.7), 0.25, 0)[0], _octahedron((0.2, 0.3, -0.7), 0.2, 2)[0]]
+    m = S.Mesh.merged(parts)
+    assert len(m.tris) == len(parts[0].tris) + 16 and m.tris["materialIndex"][-1] == 2 and m.tris["materialIndex"][0] == 3
+    sc = S.default_scene(m)
+    W, H = 160, 88
+    r = make(capi, sc, cameras["bench"], W, H, 6)
+    r.set_tuning(0, 0, 0, variant)
+    r.render(1, 3)
+    got = r.read_accum()
+    want = O.Oracle(sc, cameras["bench"], W, H, 6).render(1, 3)
+    assert n_diff_pixels(got, want) == 0
+    alone = make(capi, S.default_scene(parts[0]), cameras["bench"], W, H, 6)
+    alone.render(1, 3)
+    assert n_diff_pixels(alone.read_accum(), want) > 100, "the extra meshes are not in view"
+    alone.close()
+    r.close()

@@ -98,3 +98,31 @@ def test_pt_main_group_of_one_matches_batch_within_tolerance(tmp_path):
     ia, ib = np.fromfile(a, np.float32).reshape(184, 320, 4), np.fromfile(b, np.float32).reshape(184, 320, 4)
     assert np.all(ia[:, :, 3] == 1.0)
     np.testing.assert_allclose(ia[:, :, :3], ib[:, :, :3], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_pt_main_merges_added_meshes(tmp_path):
+    """--add-mesh PATH MATERIAL: the C++ Mesh(parts) constructor + the `f a/b/c` form of the OBJ reader; the image must be
+    the one the Python host renders from the same merged mesh, bit for bit"""
+    from path_tracer_amd import capi, scene as S
+    from test_gpu_parity import _octahedron
+    obj, octa, out = tmp_path / "bunny1.obj", tmp_path / "octa.obj", tmp_path / "merged.f32"
+    _write_obj(obj)
+    part, v, f = _octahedron((0.3, 0.35, 0.7), 0.25, 0)
+    with open(octa, "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(float(c) for c in p))
+        for t in f:
+            fh.write("f %d/1/1 %d/2/2 %d/3/3\n" % tuple(int(i) + 1 for i in t))
+    subprocess.run([PT_MAIN, "--mesh", str(obj), "--add-mesh", str(octa), "0", "--width", "320", "--height", "184", "--spp", "4",
+                    "--bounces", "6", "--batch", "--out", str(out)], check=True, capture_output=True, timeout=120)
+    got = np.fromfile(out, np.float32).reshape(184, 320, 4)
+    sc = S.default_scene(S.Mesh.merged([S.bunny_mesh(3), part]))
+    r = capi.Renderer(320, 184, device=0)
+    r.upload_scene(sc)
+    r.SetUniformCamera(S.bench_camera())
+    r.SetUniform1i("maxBounces", 6)
+    r.render(1, 4)
+    want = r.read_accum()
+    r.close()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

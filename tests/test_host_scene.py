@@ -59,3 +59,15 @@ def test_obj_loader_roundtrip(tmp_path):
 def test_heightfield_mesh_size():
     m = S.heightfield_mesh(16)
     assert len(m.tris) == 512
+
+
+def test_merged_mesh_keeps_order_materials_and_one_root_box():
+    from path_tracer_amd import scene as S
+    a = S.Mesh.from_arrays(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), np.array([[0, 1, 2]]), 3)
+    b = S.Mesh.from_arrays(np.array([[2, 2, 2], [3, 2, 2], [2, 5, -1]], np.float32), np.array([[0, 1, 2], [2, 1, 0]]), 1)
+    m = S.Mesh.merged([a, b])
+    assert list(m.tris["materialIndex"]) == [3, 1, 1] and len(m.nodes) == 1 and int(m.nodes["numTris"][0]) == 3
+    assert np.array_equal(m.nodes["boundsMin"][0][:3], np.array([0, 0, -1], np.float32))
+    assert np.array_equal(m.nodes["boundsMax"][0][:3], np.array([3, 5, 2], np.float32))
+    assert np.array_equal(m.tris[1:], b.tris) and np.array_equal(m.tris[:1], a.tris)
+    assert len(S.Mesh.merged([]).tris) == 0
