@@ -78,7 +78,7 @@ struct pt_ctx {
     float mesh_scale = 0.0f, sph_scale = 0.0f; int mesh_depth = 0, sph_depth = 0;
     bool bvh_ok = false;               // the traversal variants can run (something to traverse, nothing the builder refused in the mesh)
     float bvh_scale = 0.0f; int bvh_depth = 0, bvh_n_nodes = 0, sph_root = -1;
-    DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, counters;
+    DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, mat_fres, counters;
     int n_mesh = 0, n_chunks = 0, n_tris = 0, n_sph = 0, n_mats = 0;
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
     bool have_mesh = false, have_scene = false, have_camera = false;
@@ -151,7 +151,7 @@ SceneView scene_view(const pt_ctx *c)
     s.tri_e2 = (const float4 *)c->tri_e2.p; s.tri_nrm = (const float4 *)c->tri_nrm.p;
     s.n_tris = c->n_tris;
     s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
-    s.mats = (const PtMaterial *)c->mats.p;
+    s.mats = (const PtMaterial *)c->mats.p; s.mat_fres = (const float4 *)c->mat_fres.p;
     s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
     s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root;
     return s;
@@ -373,7 +373,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->group_comm) (void)pt_group_finalize(c);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->mat_fres, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
@@ -509,6 +509,19 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     HIPCHK(c, c->sph.upload(sp.data(), sp.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->sph_mat.upload(sm.data(), sm.size() * sizeof(uint32_t), c->stream));
     HIPCHK(c, c->mats.upload(mats, (size_t)n_mats * sizeof(PtMaterial), c->stream));
+    // what FresnelReflectAmount (rt.comp:235-254) divides, per material: host floats are IEEE binary32 and this file
+    // is built without contraction, so these are the values the kernel's own divisions would produce
+    std::vector<float> fres((size_t)std::max(1, n_mats) * 4, 0.0f);     // lives until the stream is synchronised below
+    {
+        for (int i = 0; i < n_mats; i++) {
+            volatile float n2 = mats[i].ior;
+            volatile float n1 = 1.0f / n2;                         // front face: ior = 1 / material.ior (rt.comp:281)
+            volatile float q = (n1 - n2) / (n1 + n2);
+            volatile float qb = (n2 - n2) / (n2 + n2);             // back face: n1 = n2 = material.ior
+            fres[4 * i + 0] = n1; fres[4 * i + 1] = q * q; fres[4 * i + 2] = n1 / n2; fres[4 * i + 3] = qb * qb;
+        }
+        HIPCHK(c, c->mat_fres.upload(fres.data(), fres.size() * sizeof(float), c->stream));
+    }
     // sphere tree for the traversal variants (records in leaf order: (centre, radius), (bits(index), 0, 0, 0))
     c->sph_bvh_ok = false; c->nodes_dirty = true;
     std::vector<float4> srec;

@@ -51,6 +51,7 @@ struct SceneView {
     const uint32_t *sph_mat;
     int n_sph;
     const PtMaterial *mats;   // SSBO 3
+    const float4 *mat_fres;   // per material, computed on the host with the same IEEE operations: 1/ior, r0 and n1/n2 of a front-face hit (pt_math.hpp fresnel_reflect_amount)
     // BVH over the mesh triangles (pt_bvh.hpp), used by the traversal variant
     const float4 *bvh_nodes;  // 4 x float4 per inner node: both child boxes + child codes
     const float4 *bvh_tris;   // 3 x float4 per triangle in leaf order: (p1, bits(original index)), e1, e2
@@ -890,9 +891,12 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             ps.bounces++;
                             const PtMaterial *m = &sc.mats[h.mat];
                             const float m_ior = m->ior, m_smooth = m->smoothness;
-                            const float ior = h.front ? exact_rcp(m_ior) : m_ior;
+                            // FresnelReflectAmount(n1 = ior, n2 = m_ior) (rt.comp:235-254, :283): its two divisions and the 1/ior of
+                            // rt.comp:281 depend on the material only -- taken from the host's table (same IEEE operations)
+                            const float4 mf = sc.mat_fres[h.mat];
+                            const float ior = h.front ? mf.x : m_ior;
                             const bool is_spec = m->specularChance > random_value(ps.rng);
-                            const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);
+                            const float fres = fresnel_reflect_amount_pre(h.front ? mf.y : mf.w, ior > m_ior, mf.z, h.normal, ps.d, 1.0f - m->refractionAmount);
                             const bool is_refr = fres < random_value(ps.rng);
                             const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
                             const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);

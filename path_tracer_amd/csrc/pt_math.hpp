@@ -55,7 +55,12 @@ __device__ __forceinline__ float pt_logf(float x)
     uint32_t u = __float_as_uint(x);
     float logexp = (float)((int32_t)((u & 0x7f800000u) >> 23) - 127);
     float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
-    float y = (m - 1.0f) / (m + 1.0f);
+    // y = (m - 1) / (m + 1): v_rcp_f32 + one residual correction equals the IEEE quotient for every m in [1, 2) -- all
+    // 2^23 of them checked by tools/div_exact.hip (profiles/div_exact_mi355x.txt); 4 instructions instead of 12
+    const float ya = m - 1.0f, yb = m + 1.0f;
+    const float yr = __builtin_amdgcn_rcpf(yb);
+    const float yq = ya * yr;
+    float y = fmaf(fmaf(-yb, yq, ya), yr, yq);
     float z = y * y;
     const float c0 = (float)2.88539009343309178325, c1 = (float)0.961791550404184197881, c2 = (float)0.577440339438736392009,
                 c3 = (float)0.403343858251329912514, c4 = (float)0.406718052498846252698;
@@ -242,6 +247,20 @@ __device__ __forceinline__ float fresnel_reflect_amount(float n1, float n2, v3 n
     float cosX = -dot(normal, incident);
     if (n1 > n2) {
         float n = n1 / n2;
+        float sinT2 = (n * n) * (1.0f - cosX * cosX);
+        if (sinT2 > 1.0f) return 1.0f;
+        cosX = sqrtf(1.0f - sinT2);
+    }
+    float x = 1.0f - cosX;
+    float ret = r0 + (((((1.0f - r0) * x) * x) * x) * x) * x;
+    return reflectivity + (1.0f - reflectivity) * ret;
+}
+
+// The same with r0 = ((n1-n2)/(n1+n2))^2 and n = n1/n2 supplied (they depend on the material and the face only).
+__device__ __forceinline__ float fresnel_reflect_amount_pre(float r0, bool n1_gt_n2, float n, v3 normal, v3 incident, float reflectivity)
+{
+    float cosX = -dot(normal, incident);
+    if (n1_gt_n2) {
         float sinT2 = (n * n) * (1.0f - cosX * cosX);
         if (sinT2 > 1.0f) return 1.0f;
         cosX = sqrtf(1.0f - sinT2);

@@ -37,6 +37,8 @@ def test_group_of_one_equals_sum_then_scale(capi, cameras, scenes):
     got = a.read_accum()
     a.group_render(1, 8)                  # a second, smaller collective on the same communicator
     got8 = a.read_accum()
+    a.group_render(5, 3)                  # few passes: the short-launch kernels (running sum in registers)
+    got3 = a.read_accum()
     a.group_finalize()
     a.group_finalize()                    # idempotent
     a.reset()
@@ -47,11 +49,16 @@ def test_group_of_one_equals_sum_then_scale(capi, cameras, scenes):
     a.render_sum(1, 8)
     a.scale_accum(1.0 / 8)
     want8 = a.read_accum()
+    a.reset()
+    a.render_sum(5, 3)
+    a.scale_accum(1.0 / 3)
+    want3 = a.read_accum()
     a.close()
     assert np.all(got[:, :, 3] == 1.0)
     # same kernels, same order of additions: bit-identical, not just close
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(got8.view(np.uint32), want8.view(np.uint32))
+    assert np.array_equal(got3.view(np.uint32), want3.view(np.uint32)) and np.all(got3[:, :, 3] == 1.0)
 
 
 def test_group_bad_arguments(capi):
