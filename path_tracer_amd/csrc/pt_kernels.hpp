@@ -918,7 +918,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
                         }
                         const float nb = (float)ps.bounces;
-                        colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
+                        colour = div_small_int(ps.incoming, nb);   // rt.comp:322
                     }
                     if (done) {
                         if (SHORT) {
@@ -947,7 +947,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     if (fresh) ps.rng = (uint32_t)(fp.first_pass + k) * pix_seed;       // rt.comp:327
                     const float gx = random_value_nd(ps.rng), gy = random_value_nd(ps.rng), gz = random_value_nd(ps.rng);
                     const v3 g = V(gx, gy, gz);
-                    const float gr = exact_rcp(sqrtf(dot(g, g)));        // normalize(v) = v * (1/sqrt(dot(v,v)))
+                    const float gr = exact_rcp(exact_sqrt(dot(g, g)));        // normalize(v) = v * (1/sqrt(dot(v,v)))
                     if (fresh) {
                         // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
                         const v3 jit = (g * 0.00025f) * gr;

@@ -25,7 +25,18 @@ __device__ __forceinline__ float dot(v3 a, v3 b) { return (a.z * b.z + a.y * b.y
 __device__ __forceinline__ v3 cross(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 // normalize(v) = v * (1/sqrt(dot(v,v)))
 __device__ __forceinline__ float exact_rcp(float x);
-__device__ __forceinline__ v3 normalize(v3 v) { float r = exact_rcp(sqrtf(dot(v, v))); return v * r; }
+// Correctly rounded sqrt in 5 instructions: s = x * v_rsq_f32(x), then one fused residual step s + (x - s*s) * (rsq/2).
+// Equal to sqrtf(x) for EVERY x in [2^-64, inf) -- all 1.6e9 of them compared by tools/sqrt_exact.hip
+// (profiles/sqrt_exact_mi355x.txt); anything else (0, tiny, negative, inf, NaN) takes the IEEE expansion.
+__device__ __forceinline__ float exact_sqrt(float x)
+{
+    const float rs = __builtin_amdgcn_rsqf(x);
+    const float sb = x * rs;
+    float s = fmaf(fmaf(-sb, sb, x), 0.5f * rs, sb);
+    if (__builtin_expect(!((__float_as_uint(x) - 0x1f800000u) < 0x60000000u), 0)) s = sqrtf(x);
+    return s;
+}
+__device__ __forceinline__ v3 normalize(v3 v) { float r = exact_rcp(exact_sqrt(dot(v, v))); return v * r; }
 // mix(x,y,t) with a dynamic t = x + t*(y-x)
 __device__ __forceinline__ float mixf(float x, float y, float t) { return x + t * (y - x); }
 __device__ __forceinline__ v3 mix3(v3 x, v3 y, float t) { return V(mixf(x.x, y.x, t), mixf(x.y, y.y, t), mixf(x.z, y.z, t)); }
@@ -110,7 +121,7 @@ __device__ __forceinline__ float pt_cosf(float a)
 __device__ __forceinline__ float random_value_nd(uint32_t &state)
 {
     float theta = kTwoPi * random_value(state);
-    float rho = sqrtf(-2.0f * pt_logf(random_value(state)));
+    float rho = exact_sqrt(-2.0f * pt_logf(random_value(state)));
     return rho * pt_cosf(theta);
 }
 
@@ -230,7 +241,7 @@ __device__ __forceinline__ bool hit_sphere(v3 c, float radius, v3 o, v3 d, float
     float hb = dot(oc, d);
     float cc = dot(oc, oc) - radius * radius;
     float disc = hb * hb - a * cc;
-    float sq = sqrtf(disc);
+    float sq = exact_sqrt(disc);
     float t0 = (-hb - sq) / a;
     float t1 = (-hb + sq) / a;
     bool front = t0 > 0.0f;
@@ -249,7 +260,7 @@ __device__ __forceinline__ float fresnel_reflect_amount(float n1, float n2, v3 n
         float n = n1 / n2;
         float sinT2 = (n * n) * (1.0f - cosX * cosX);
         if (sinT2 > 1.0f) return 1.0f;
-        cosX = sqrtf(1.0f - sinT2);
+        cosX = exact_sqrt(1.0f - sinT2);
     }
     float x = 1.0f - cosX;
     float ret = r0 + (((((1.0f - r0) * x) * x) * x) * x) * x;
@@ -263,11 +274,25 @@ __device__ __forceinline__ float fresnel_reflect_amount_pre(float r0, bool n1_gt
     if (n1_gt_n2) {
         float sinT2 = (n * n) * (1.0f - cosX * cosX);
         if (sinT2 > 1.0f) return 1.0f;
-        cosX = sqrtf(1.0f - sinT2);
+        cosX = exact_sqrt(1.0f - sinT2);
     }
     float x = 1.0f - cosX;
     float ret = r0 + (((((1.0f - r0) * x) * x) * x) * x) * x;
     return reflectivity + (1.0f - reflectivity) * ret;
+}
+
+// a / b for an integer-valued b in [1, 256] (`incoming / bounces`, rt.comp:322): v_rcp_f32 + one residual correction is the
+// IEEE quotient whenever the result is a normal number -- every a x b = 1..256 compared by tools/sqrt_exact.hip; +0 / b
+// = +0 holds trivially.  Other lanes (denormal or non-finite results, -0, b out of range) take the IEEE division.
+__device__ __forceinline__ v3 div_small_int(v3 a, float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float x0 = a.x * r, y0 = a.y * r, z0 = a.z * r;
+    v3 q = V(fmaf(fmaf(-b, x0, a.x), r, x0), fmaf(fmaf(-b, y0, a.y), r, y0), fmaf(fmaf(-b, z0, a.z), r, z0));
+    const bool ok = (__builtin_amdgcn_classf(q.x, 0x108) || __float_as_uint(a.x) == 0u) && (__builtin_amdgcn_classf(q.y, 0x108) || __float_as_uint(a.y) == 0u)
+                    && (__builtin_amdgcn_classf(q.z, 0x108) || __float_as_uint(a.z) == 0u) && b >= 1.0f && b <= 256.0f;
+    if (__builtin_expect(!ok, 0)) q = V(a.x / b, a.y / b, a.z / b);
+    return q;
 }
 
 __device__ __forceinline__ v3 reflect3(v3 i, v3 n) { float k = 2.0f * dot(n, i); return i - n * k; }
@@ -277,7 +302,7 @@ __device__ __forceinline__ v3 refract3(v3 i, v3 n, float eta)
     float d = dot(n, i);
     float k = 1.0f - eta * (eta * (1.0f - d * d));
     if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
-    float c = eta * d + sqrtf(k);
+    float c = eta * d + exact_sqrt(k);
     return i * eta - n * c;
 }
 
