@@ -54,7 +54,7 @@ struct pt_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<hipEvent_t> ev;        // pairs (before, after) around every pt_trace_items launch of the last render
     int n_timed = 0;
-    DevBuf radiance;                   // [batch passes][H][W] float4 workspace
+    DevBuf radiance;                   // [batch passes][H][W] Rgb workspace (12 B per sample)
     size_t workspace_limit = (size_t)4 << 30;
     int chunk_passes = 4;              // passes per work item (mesh tiles; others take multiples)
     DevBuf queue;                      // work-item counter of pt_trace_items
@@ -170,7 +170,7 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     f.traced_width = (c->width / 8) * 8; f.rows = (c->height / 8) * 8;
     f.x_blocks = (f.traced_width + kWave - 1) / kWave;
     f.accum = c->accum;
-    f.radiance = (float4 *)c->radiance.p;
+    f.radiance = (Rgb *)c->radiance.p;
     f.counters = (unsigned long long *)c->counters.p;
     return f;
 }
@@ -229,7 +229,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     if (first_pass < 0 || n_passes < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, n_passes);
     Bind b(c); HIPCHK(c, b.e);
     if ((rc = sync_bvh(c)) != PT_OK) return rc;
-    const size_t plane_bytes = (size_t)c->width * c->height * sizeof(float4);
+    const size_t plane_bytes = (size_t)c->width * c->height * sizeof(Rgb);
     // The traversal kernels (variants 5, 6) schedule lane by lane, so one lane can take ALL passes of a pixel and keep the
     // running mean in registers: no per-pass workspace, no accumulate kernel.  Only for short pass ranges (interactive
     // use: one or a few passes per call): a lane task of 64 passes of a hard pixel runs for milliseconds and, started late,

@@ -60,6 +60,9 @@ struct SceneView {
     int sph_root;             // node index of the sphere tree's root in bvh_nodes, -1: spheres are scanned one by one
 };
 
+// one sample's radiance in the workspace: three floats (the alpha the shader stores is the constant 1)
+struct __attribute__((aligned(4))) Rgb { float r, g, b; };
+
 struct FrameParams {
     int width, height;
     float cam[3];
@@ -70,7 +73,7 @@ struct FrameParams {
     int traced_width, rows, x_blocks;   // (W/8)*8, (H/8)*8 (glDispatchCompute(W/8, H/8, 1)), ceil(traced_width/64)
     int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
     float *accum;             // RGBA32F, row 0 = bottom
-    float4 *radiance;         // [n_passes][H][W] 1-spp radiance of this batch
+    Rgb *radiance;            // [n_passes][H][W] 1-spp radiance of this batch, 12 B per sample
     unsigned *queue;          // work-item counter, zeroed before every launch
     // schedule (pt_tile_weights + pt_sort_tiles): tiles = 64 px of a row, sorted heaviest first, in three classes
     const unsigned *order;    // [n_tiles] tile index by rank
@@ -574,7 +577,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         const int x = xb * kWave + lane;
         const bool valid = x < fp.traced_width;
         const int k_end = min(fp.n_passes, (chunk + 1) * ppi);
-        float4 *rad = fp.radiance + (size_t)y * fp.width + x;
+        Rgb *rad = fp.radiance + (size_t)y * fp.width + x;
         int k = chunk * ppi;                                           // pass index relative to fp.first_pass
         bool fresh = true;                                             // lane needs the primary ray of pass k
         PathState ps;
@@ -614,7 +617,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
                     colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
                 }
                 if (done) {
-                    rad[(size_t)k * plane] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                    rad[(size_t)k * plane] = Rgb{colour.x, colour.y, colour.z};
                     k++;
                     fresh = true;
                 }
@@ -926,7 +929,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             if (fp.sum_mode) acc = acc + colour;
                             else acc = mix3(acc, colour, exact_rcp((float)(fp.first_pass + k)));
                         } else {
-                            fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = make_float4(colour.x, colour.y, colour.z, 1.0f);
+                            fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = Rgb{colour.x, colour.y, colour.z};
                         }
                         k++;
                         state = k < k_end ? S_FRESH : S_DEAD;
@@ -1168,16 +1171,24 @@ __global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
     float4 *px = reinterpret_cast<float4 *>(fp.accum) + pix;
     const float4 prev = *px;
     v3 acc = V(prev.x, prev.y, prev.z);
-    const float4 *rad = fp.radiance + pix;
-    for (int k = 0; k < fp.n_passes; k++) {
-        const float4 c = rad[(size_t)k * plane];
+    const Rgb *rad = fp.radiance + pix;
+    auto apply = [&](const Rgb c, int k) {
         if (fp.sum_mode) {
-            acc = acc + V(c.x, c.y, c.z);
+            acc = acc + V(c.r, c.g, c.b);
         } else {
             const float t = 1.0f / (float)(fp.first_pass + k);          // rt.comp:337
-            acc = mix3(acc, V(c.x, c.y, c.z), t);
+            acc = mix3(acc, V(c.r, c.g, c.b), t);
         }
+    };
+    int k = 0;
+    for (; k + 8 <= fp.n_passes; k += 8) {                              // eight independent loads in flight per thread
+        Rgb c[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) c[j] = rad[(size_t)(k + j) * plane];
+#pragma unroll
+        for (int j = 0; j < 8; j++) apply(c[j], k + j);
     }
+    for (; k < fp.n_passes; k++) apply(rad[(size_t)k * plane], k);
     *px = make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? prev.w + (float)fp.n_passes : 1.0f);
 }
 

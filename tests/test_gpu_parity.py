@@ -257,7 +257,7 @@ def test_workspace_batches_and_item_sizes_do_not_change_results(capi, cameras, s
     ref = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
     ref.render(1, SPP)
     want = ref.read_accum()
-    for chunk, limit in ((1, 0), (3, 0), (64, 0), (4, 3 * W * H * 16), (2, 1)):
+    for chunk, limit in ((1, 0), (3, 0), (64, 0), (4, 3 * W * H * 12), (2, 1)):     # 12 B per sample in the workspace: 3 passes per batch -> 4 launches
         r = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
         r.set_tuning(chunk, limit, 0, 4)       # brute-force kernel: per-pass workspace + pt_accumulate
         r.render(1, SPP)
