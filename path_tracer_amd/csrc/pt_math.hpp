@@ -118,11 +118,66 @@ __device__ __forceinline__ float pt_cosf(float a)
 }
 
 // rt.comp:79-83: theta is drawn first, then rho
-__device__ __forceinline__ float random_value_nd(uint32_t &state)
+__device__ __forceinline__ float random_value_nd_generic(uint32_t &state)
 {
     float theta = kTwoPi * random_value(state);
     float rho = exact_sqrt(-2.0f * pt_logf(random_value(state)));
     return rho * pt_cosf(theta);
+}
+// The two factors are functions of ONE 32-bit draw each, so their special-case handling can be cut down to what those
+// 2^32 inputs need: theta = 2 pi u / 2^32 is finite and >= 0 and the polynomial result never leaves [-1, 1] (no NaN
+// test, no clamp); u / 2^32 <= 1 (no +inf test in log).  tools/nd_exact.hip compares both with pt_cosf / pt_logf on every
+// u (profiles/nd_exact_mi355x.txt).
+__device__ __forceinline__ float nd_cos_of_draw(uint32_t r)
+{
+    const float a = kTwoPi * ((float)r / 4294967296.0f);
+    const float scale_y = a * (float)1.27323954473516;
+    int32_t j = (int32_t)scale_y;
+    j = (j + 1) & ~1;
+    const float y = (float)j;
+    const int32_t j2 = j - 2;
+    const uint32_t sign_bit = ((uint32_t)(4 & ~j2)) << 29;
+    const bool use_sin_poly = (j2 & 2) == 0;
+    float x = fmaf(y, (float)-0.78515625, a);
+    x = fmaf(y, (float)-2.4187564849853515625e-4, x);
+    x = fmaf(y, (float)-3.77489497744594108e-8, x);
+    const float z = x * x;
+    float yc = fmaf(z, (float)2.443315711809948E-005, (float)-1.388731625493765E-003);
+    yc = fmaf(yc, z, (float)4.166664568298827E-002);
+    yc = yc * z;
+    yc = yc * z;
+    yc = yc - z * 0.5f;
+    yc = yc + 1.0f;
+    float ys = fmaf(z, (float)-1.9515295891E-4, (float)8.3321608736E-3);
+    ys = fmaf(ys, z, (float)-1.6666654611E-1);
+    ys = ys * z;
+    ys = fmaf(ys, x, x);
+    return __uint_as_float(__float_as_uint(use_sin_poly ? ys : yc) ^ sign_bit);
+}
+__device__ __forceinline__ float nd_rho_of_draw(uint32_t r)
+{
+    const float x = (float)r / 4294967296.0f;
+    const uint32_t u = __float_as_uint(x);
+    const float logexp = (float)((int32_t)(u >> 23) - 127);             // x >= 0: no sign bit to mask
+    const float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    const float ya = m - 1.0f, yb = m + 1.0f;
+    const float yr = __builtin_amdgcn_rcpf(yb);
+    const float yq = ya * yr;
+    const float y = fmaf(fmaf(-yb, yq, ya), yr, yq);
+    const float z = y * y;
+    const float c0 = (float)2.88539009343309178325, c1 = (float)0.961791550404184197881, c2 = (float)0.577440339438736392009,
+                c3 = (float)0.403343858251329912514, c4 = (float)0.406718052498846252698;
+    const float z2 = z * z;
+    const float even = fmaf(z2, fmaf(z2, c4, c2), c0);
+    const float odd = fmaf(z2, c3, c1);
+    float res = fmaf(y, fmaf(odd, z, even), logexp);
+    if (x == 0.0f) res = -__builtin_inff();
+    return exact_sqrt(-2.0f * (res * (float)0.69314718055994529));
+}
+__device__ __forceinline__ float random_value_nd(uint32_t &state)
+{
+    const uint32_t r_theta = next_random(state), r_rho = next_random(state);
+    return nd_rho_of_draw(r_rho) * nd_cos_of_draw(r_theta);
 }
 
 // rt.comp:85-90
