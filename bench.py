@@ -130,7 +130,13 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # PT_BENCH_FORCE_SPLIT=1: take the N > 1 code path (process group on RCCL, sum render, reduce, scale) with whatever
+    # world size the launcher gave, 1 included -- how the RCCL leg is exercised on a one-GPU box (not a measurement)
+    split = world > 1 or os.environ.get("PT_BENCH_FORCE_SPLIT") == "1"
+    if split and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+    if split:
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -151,22 +157,22 @@ def main():
     r.set_accum_buffer(accum.data_ptr(), accum.numel() * 4)
     r.set_stream(stream.cuda_stream)
 
-    def step():
-        if world == 1:
+    def step(check=False):
+        if not split:
             accum.zero_()
             r.render(1, SPP)                                                 # reference semantics, bit-exact
         else:
             # rank g traces passes g*SPP+1 .. (g+1)*SPP as a sum; ONE reduce onto rank 0 (RCCL over xGMI); rank 0 scales
-            D.render_split(r, accum, SPP * world)
+            D.render_split(r, accum, SPP * world, check=check)       # the sample-count check synchronises: warm-up only
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if split:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        step()
+        step(check=True)
     fence()
     r.reset_counters()
     durs = []
@@ -179,7 +185,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if split:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -190,9 +196,9 @@ def main():
     achieved = flops_per_launch / (k_ms * 1e-3) / 1e12
     kernel_name = {0: capi.load().pt_kernel_name().decode(), 1: "pt_trace_items", 5: "pt_trace_items_bvh", 6: "pt_trace_items_bvh_lds"}.get(a.variant, "pt_trace_items_lds")
 
-    final_image = accum.cpu().numpy() if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
+    final_image = accum.cpu().numpy() if (rank == 0 and not split and not a.no_cpu_baseline) else None
     brute = None
-    if rank == 0 and world == 1 and not a.no_brute_force and kernel_name.startswith("pt_trace_items_bvh"):
+    if rank == 0 and not split and not a.no_brute_force and kernel_name.startswith("pt_trace_items_bvh"):
         # outside the timed region: the same render on the brute-force kernel (exact by construction), to show what the
         # BVH buys and that both give the same image bit for bit
         img = accum.clone()
@@ -221,7 +227,7 @@ def main():
             "config": {"workload": "configs[1]: default res/meshes scene (bunny1 656 tris + 2 scene tris), 1920x1080, "
                                    f"{SPP} spp per GPU, {BOUNCES} bounces, camera (1.5,0.4,0) yaw 0 pitch 0",
                        "width": W, "height": H, "spp_per_gpu": SPP, "spp_total": SPP * world, "max_bounces": BOUNCES,
-                       "parallelism": "spp-split x%d + 1 RCCL reduce/render" % world if world > 1 else "single GPU"},
+                       "parallelism": "spp-split x%d + 1 RCCL reduce/render" % world if split else "single GPU"},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VALU_PEAK_TFLOPS, **profiled_traffic(kernel_name),
                          "kernel": kernel_name, "kernel_ms": k_ms,
@@ -239,10 +245,10 @@ def main():
         }
         if brute:
             out["brute_force_kernel"] = brute
-        if world == 1 and not a.no_cpu_baseline:
+        if not split and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, cam, final_image)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if split:
         dist.barrier()
         dist.destroy_process_group()
     r.close()

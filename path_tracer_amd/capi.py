@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -42,6 +43,30 @@ class PtError(RuntimeError):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so (torch/lib), and two HIP runtimes
+    in one process cannot both open the GPU: if libpt_hip.so pulled in /opt/rocm's copy first, a later `import torch`
+    brought the second one and whichever touched the card second reported "no HIP device" (seen on MI355X, ROCm 7.2 +
+    torch 2.10: tools/hip_order_diag.py).  Loading torch's copy first -- without importing torch -- makes the dynamic
+    loader resolve libpt_hip.so's libamdhip64 dependency to it, whatever the import order.  No torch installed (or no
+    bundled runtime): the system library is used, as it is by the C++ host."""
+    if "torch" in sys.modules:
+        return                                    # already in the process: the loader reuses it by SONAME
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for base in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(base, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     """dlopen libpt_hip.so and declare prototypes.  Raises if the HIP library is missing."""
     global _lib
@@ -50,6 +75,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); path_tracer_amd has no CPU fallback")
+    _share_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int, C.POINTER(C.c_float)
     L.pt_create.argtypes = [C.POINTER(vp), i32]

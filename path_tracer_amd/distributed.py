@@ -24,27 +24,33 @@ def pass_range(rank: int, world: int, total_spp: int, first_pass: int = 1):
     return first, count
 
 
-def reduce_and_finish(accum, total_spp: int, dst: int = 0, group=None):
+def reduce_and_finish(accum, total_spp: int, dst: int = 0, group=None, renderer=None, check: bool = True):
     """Sum the per-rank sum buffers onto `dst` (one collective) and turn the sum into the mean there.
     `accum`: (H, W, 4) float32 tensor holding this rank's sum (alpha = number of passes it traced).
-    Returns True on the rank that now holds the finished image."""
-    import torch
+    `renderer`: if it offers `scale_accum` (capi.Renderer), the finish is ONE library kernel (pt_scale_accum) on the
+    renderer's stream -- which must be the stream torch issues the reduce on (bench.py sets both); otherwise torch ops.
+    `check`: read the summed sample count back and compare it with total_spp (a host synchronisation: callers in a
+    timed loop switch it off after their warm-up).  Returns True on the rank that now holds the finished image."""
     import torch.distributed as dist
 
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if dist.is_initialized():
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)      # a group of one still goes through the backend
         is_root = dist.get_rank(group) == dst
     else:
         is_root = True
     if is_root:
-        if int(round(float(accum[0, 0, 3]))) != total_spp:
+        if check and int(round(float(accum[0, 0, 3]))) != total_spp:
             raise RuntimeError(f"sample count after reduce is {float(accum[0, 0, 3])}, expected {total_spp}")
-        accum[..., :3] *= torch.tensor(1.0 / total_spp, dtype=accum.dtype, device=accum.device)
-        accum[..., 3] = 1.0
+        scale = getattr(renderer, "scale_accum", None)
+        if scale is not None:
+            scale(1.0 / total_spp, True)
+        else:
+            accum[..., :3] *= 1.0 / total_spp          # python scalar: rounded to float32 once, no host tensor
+            accum[..., 3] = 1.0
     return is_root
 
 
-def render_split(renderer, accum, total_spp: int, first_pass: int = 1, group=None):
+def render_split(renderer, accum, total_spp: int, first_pass: int = 1, group=None, check: bool = True):
     """One multi-GPU render: zero, trace this rank's passes as a sum into `accum` (the tensor registered with
     renderer.set_accum_buffer), reduce, finish on rank 0.  Returns True on rank 0."""
     import torch.distributed as dist
@@ -55,4 +61,4 @@ def render_split(renderer, accum, total_spp: int, first_pass: int = 1, group=Non
     accum.zero_()
     if count:
         renderer.render_sum(first, count)
-    return reduce_and_finish(accum, total_spp, 0, group)
+    return reduce_and_finish(accum, total_spp, 0, group, renderer, check)

@@ -23,3 +23,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "pt_oracle" not in txt and "libpt_oracle" not in txt, f
+
+
+import subprocess
+import sys
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["load,torch,capi", "capi,torch,capi", "torch,capi"])
+def test_one_hip_runtime_whatever_the_import_order(order):
+    """torch wheels bundle a HIP runtime of their own; capi.load() must end up on the same one as torch in either import
+    order, or the second of the two to touch the GPU finds no device (tools/hip_order_diag.py, fresh process per order)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hip_order_diag.py"), order], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "capi ok" in r.stdout and "torch ok" in r.stdout and "FAILED" not in r.stdout, r.stdout
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.count("libamdhip64") == 1, last
