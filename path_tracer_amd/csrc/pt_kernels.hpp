@@ -1181,12 +1181,25 @@ __global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
         }
     };
     int k = 0;
-    for (; k + 8 <= fp.n_passes; k += 8) {                              // eight independent loads in flight per thread
-        Rgb c[8];
+#ifndef PT_ACC_UNROLL
+#define PT_ACC_UNROLL 8
+#endif
+#ifndef PT_ACC_NT
+#define PT_ACC_NT 1          // streaming loads: the workspace is read once (0.35 -> 0.30 ms at 1080p x 64)
+#endif
+    for (; k + PT_ACC_UNROLL <= fp.n_passes; k += PT_ACC_UNROLL) {      // independent loads in flight per thread
+        Rgb c[PT_ACC_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; j++) c[j] = rad[(size_t)(k + j) * plane];
+        for (int j = 0; j < PT_ACC_UNROLL; j++) {
+            const Rgb *q = rad + (size_t)(k + j) * plane;
+#if PT_ACC_NT
+            c[j] = Rgb{__builtin_nontemporal_load(&q->r), __builtin_nontemporal_load(&q->g), __builtin_nontemporal_load(&q->b)};
+#else
+            c[j] = *q;
+#endif
+        }
 #pragma unroll
-        for (int j = 0; j < 8; j++) apply(c[j], k + j);
+        for (int j = 0; j < PT_ACC_UNROLL; j++) apply(c[j], k + j);
     }
     for (; k < fp.n_passes; k++) apply(rad[(size_t)k * plane], k);
     *px = make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? prev.w + (float)fp.n_passes : 1.0f);
