@@ -139,7 +139,7 @@ int pt_reset_counters(pt_ctx *ctx);
  * the most recent pt_render / pt_render_pass / pt_render_sum call, summed over its launches (one per
  * workspace batch; the count goes to *n_launches if not NULL); waits for them to finish. */
 int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
-/* Tuning knobs (0 = keep): passes per work item (default 2), the byte limit of the per-pass radiance
+/* Tuning knobs (0 = keep): passes per work item of the mesh tiles (default 4), the byte limit of the per-pass radiance
  * workspace [passes][H][W] x 12 B (RGB float) that bounds how many passes one launch covers (default 4 GiB), and the
  * number of persistent single-wave workgroups launched per CU (default 12 = 3 waves/SIMD), and the kernel
  * variant: 1 = brute force, mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = brute force, resident in a
