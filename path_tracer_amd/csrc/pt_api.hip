@@ -266,14 +266,20 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         fp.queue = (unsigned *)c->queue.p; fp.n_tiles = n_tiles;
         // passes per work item: mesh tiles `chunk`; tiles that only bounce off scene primitives and sky tiles take more
         // passes per item (their items are short, and every item costs one ~11 ns device-wide atomic on the queue)
-        static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 16;
+        static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 8;
         fp.class_ppi[0] = fp.chunk; fp.class_ppi[1] = std::max(1, std::min(np, mul1 * fp.chunk)); fp.class_ppi[2] = std::max(1, std::min(np, mul2 * fp.chunk));
         if (fused) fp.class_ppi[0] = fp.class_ppi[1] = fp.class_ppi[2] = np;   // SHORT kernels: every item covers all passes
-        static const int park_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 40, park_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 2;
-        static const int refill_min = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 8;
-        fp.park_high = park_high; fp.park_wait = park_wait; fp.refill_min = refill_min;
-        static const int park_exit = getenv("PT_PARK_EXIT") ? atoi(getenv("PT_PARK_EXIT")) : 2;
-        fp.park_exit = park_exit;
+        // Scheduling of the traversal kernels' lane state machine, tuned on configs 2, 3, 5, 4K and the
+        // short launches; the environment overrides them for experiments (0 / unset = these defaults).
+        //   long launches: traverse at 32 parked lanes or after 4 iterations of waiting, leave the traversal phase with 3/8
+        //   of its rays unfinished, refill at 4 idle lanes; short launches (tail-bound) and scenes with a sphere tree
+        //   (every ray traverses) keep the earlier, more eager settings where those measured better.
+        static const int e_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 0, e_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 0;
+        static const int e_refill = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 0, e_exit = getenv("PT_PARK_EXIT") ? atoi(getenv("PT_PARK_EXIT")) : 0;
+        fp.park_high = e_high ? e_high : (fused ? 40 : 32);
+        fp.park_wait = e_wait ? e_wait : (fused ? 2 : 4);
+        fp.refill_min = e_refill ? e_refill : (fused ? 8 : 4);
+        fp.park_exit = e_exit ? e_exit : ((fused || c->sph_root >= 0) ? 2 : 3);
         fp.weights = (unsigned *)c->tile_weights.p; fp.order = (const unsigned *)c->tile_order.p; fp.class_count = (const int *)c->class_count.p;
         if (c->order_dirty) {
             hipLaunchKernelGGL(pt_tile_weights, dim3((unsigned)n_tiles), dim3(kWave), 0, c->stream, sv, fp);
