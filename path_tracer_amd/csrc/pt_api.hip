@@ -276,8 +276,9 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         //   (every ray traverses) keep the earlier, more eager settings where those measured better.
         static const int e_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 0, e_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 0;
         static const int e_refill = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 0, e_exit = getenv("PT_PARK_EXIT") ? atoi(getenv("PT_PARK_EXIT")) : 0;
-        fp.park_high = e_high ? e_high : (fused ? 40 : 32);
-        fp.park_wait = e_wait ? e_wait : (fused ? 2 : 4);
+        const bool big = variant0 == 5;       // BVH in global memory (large meshes: most rays traverse): larger batches
+        fp.park_high = e_high ? e_high : (fused ? 40 : big ? 48 : 32);
+        fp.park_wait = e_wait ? e_wait : (fused ? 2 : big ? 6 : 4);
         fp.refill_min = e_refill ? e_refill : (fused ? 8 : 4);
         fp.park_exit = e_exit ? e_exit : ((fused || c->sph_root >= 0) ? 2 : 3);
         fp.weights = (unsigned *)c->tile_weights.p; fp.order = (const unsigned *)c->tile_order.p; fp.class_count = (const int *)c->class_count.p;
