@@ -455,3 +455,20 @@ def test_merged_meshes_with_their_own_materials_vs_oracle(capi, cameras, variant
     assert n_diff_pixels(alone.read_accum(), want) > 100, "the extra meshes are not in view"
     alone.close()
     r.close()
+
+
+@pytest.mark.parametrize("size", [(8, 8), (72, 40), (100, 61), (200, 95), (333, 17)])
+@pytest.mark.parametrize("spp", [2, 6])
+def test_ragged_image_sizes_vs_oracle(capi, cameras, scenes, size, spp):
+    """widths that are not a multiple of the 64-pixel tile (partly filled last tile), sizes that are not a multiple of the 8x8
+    dispatch group (untouched border), the 8x8 minimum; 2 spp takes the short-launch kernels, 6 spp the workspace path"""
+    import oracle_py as O
+    W, H = size
+    r = make(capi, scenes["mixed"], cameras["mixed"], W, H, 5)
+    r.render(1, spp)
+    got = r.read_accum()
+    want = O.Oracle(scenes["mixed"], cameras["mixed"], W, H, 5).render(1, spp)
+    tw, th = (W // 8) * 8, (H // 8) * 8
+    assert n_diff_pixels(got[:th, :tw], want[:th, :tw]) == 0
+    assert np.all(got[th:, :, :] == 0) and np.all(got[:, tw:, :] == 0)
+    r.close()
