@@ -123,3 +123,39 @@ def test_axis_parallel_rays_and_degenerate_triangles(capi):
         img, _ = render(capi, sc, cam, W, H, B, SPP, variant)
         assert bits_equal(img, ref), (variant, n_diff_pixels(img, ref))
     assert n_diff_pixels(ref, O.Oracle(sc, cam, W, H, B).render(1, SPP)) == 0
+
+
+def _same_or_both_nan(a, b):
+    """bitwise equality, except that any NaN equals any NaN (x86 and gfx950 produce default NaNs of opposite sign)"""
+    au, bu = a.view(np.uint32), b.view(np.uint32)
+    return (au == bu) | (np.isnan(a) & np.isnan(b))
+
+
+def test_extreme_materials_take_the_ieee_fallbacks(capi):
+    """materials whose numbers leave the ranges the short exact forms cover: ior 0 / negative / huge / tiny (Fresnel table with
+    inf and NaN entries, refraction with NaN eta), emission that overflows to inf (inf / bounces, inf - inf) or stays
+    denormal (denormal / bounces): every variant must still equal the oracle bit for bit, NaNs matching NaNs"""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    mats = [S.material(baseColor=(0.8, 0.8, 0.8, 1), emissionColor=(0, 0, 0, 0), smoothness=0.5, ior=v, refractionAmount=0.7, specularChance=0.3)
+            for v in (0.0, -1.5, 1e30, 1e-30, 1.0)]
+    mats.append(S.material(baseColor=(1, 1, 1, 1), emissionColor=(1, 0.5, 0.25, 1), emissionStrength=3e38))     # overflows when summed
+    mats.append(S.material(baseColor=(1, 1, 1, 1), emissionColor=(1, 0.5, 0.25, 1), emissionStrength=1e-42))    # denormal radiance
+    mats.append(S.material(baseColor=(0.9, 0.9, 0.9, 1), emissionColor=(0, 0, 0, 0)))                            # ground
+    sc = S.Scene(materials=np.stack(mats), mesh=S.bunny_mesh(4))
+    sc.add_triangle((-50, 0, 50), (50, 0, 50), (0, 0, -50), 7)
+    sc.add_triangle((-1, 0, 3), (1, 0, 3), (0, 1.4, 3), 5)
+    sc.add_triangle((-1, 0, -3), (1, 0, -3), (0, 1.4, -3), 6)
+    for i in range(7):
+        sc.add_sphere((0.9 * np.cos(i), 0.25 + 0.1 * i, 0.9 * np.sin(i)), 0.2, i)
+    cam = S.Camera(position=np.array([2.2, 0.8, 0.3], np.float32), yaw=5.0, pitch=12.0).UpdateView()
+    W, H, B, SPP = 128, 72, 8, 6
+    want = O.Oracle(sc, cam, W, H, B).render(1, SPP)
+    assert np.isnan(want).any() or np.isinf(want).any(), "the scene does not reach the non-finite paths"
+    for variant in (1, 6, 5):
+        got, _ = render(capi, sc, cam, W, H, B, SPP, variant)
+        bad = int((~_same_or_both_nan(got, want)).any(-1).sum())
+        assert bad == 0, (variant, bad)
+    short, _ = render(capi, sc, cam, W, H, B, 2, 6)          # short-launch kernels
+    want2 = O.Oracle(sc, cam, W, H, B).render(1, 2)
+    assert int((~_same_or_both_nan(short, want2)).any(-1).sum()) == 0
