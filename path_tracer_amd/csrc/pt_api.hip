@@ -713,6 +713,7 @@ int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
 }
 
 // ---- RCCL, resolved at run time ------------------------------------------------------------------------------
+extern "C++" {
 namespace {
 struct Rccl {
     typedef struct { char internal[PT_GROUP_ID_BYTES]; } UniqueId;            // ncclUniqueId (rccl.h:43)
@@ -744,6 +745,7 @@ Rccl &rccl()
 }
 constexpr int kNcclFloat32 = 7, kNcclSum = 0;                                   // rccl.h:448,466
 }  // namespace
+}  // extern "C++"
 
 int pt_group_unique_id(char id[PT_GROUP_ID_BYTES])
 {
