@@ -120,6 +120,11 @@ __device__ __forceinline__ float4 uniform_load(const float4 *p, int i)
 #endif
 }
 
+// Wave votes straight from the condition: HIP's __ballot / __any take an int, and the bool -> int -> "!= 0" round trip
+// survives optimisation in places as a v_cndmask + v_cmp pair (8 issue cycles) per vote -- two of them per traversal step.
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 // Copy a wave-uniform value into a VGPR and hide its uniformity from the compiler.  On gfx950 a VALU instruction with
 // an SGPR source issues in 4 SIMD cycles, the same mul/add/sub/fma with VGPR sources in 2 (tools/valu_mix.hip), so the
@@ -250,7 +255,7 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, Store &st, int
 #endif
             const float tmin = readlane_f(wave_min_to_lane63(lt), 63);
             if (tmin < kInfinity) {
-                const unsigned long long winners = __ballot(lt == tmin);
+                const unsigned long long winners = wave_ballot(lt == tmin);
                 const int wl = __builtin_amdgcn_readfirstlane(__builtin_ctzll(winners));
                 const int slot = __builtin_amdgcn_readlane(ls, wl);
                 const int id = chunk * (kWave * SLOTS) + wl * SLOTS + slot;
@@ -468,10 +473,10 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int
     bool gate = false;
     if (alive && sc.n_mesh > 0)
         gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), o, d);
-    const unsigned long long gate_mask = __ballot(gate);
-    n_seg += __popcll(__ballot(alive));
+    const unsigned long long gate_mask = wave_ballot(gate);
+    n_seg += __popcll(wave_ballot(alive));
     n_mesh_seg += __popcll(gate_mask);
-    n_prim_mesh_seg += __popcll(__ballot(gate && primary));
+    n_prim_mesh_seg += __popcll(wave_ballot(gate && primary));
     if constexpr (Store::is_bvh) {
         PT_TICK(b0);
         bvh_closest(sc, st, gate, o, d, h.t, h.id, n_bvh_nodes, n_bvh_tests);
@@ -584,7 +589,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
         for (;;) {
             const bool alive = valid && k < k_end;
-            if (!__any(alive)) break;
+            if (!wave_any(alive)) break;
             n_iter++;
             PT_TICK(c0);
             if (alive && fresh) {
@@ -592,12 +597,12 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
                 ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
                 fresh = false;
             }
-            n_samples += __popcll(__ballot(alive && ps.bounces == 0));
+            n_samples += __popcll(wave_ballot(alive && ps.bounces == 0));
             PT_TICK(c1);
             Hit h = calculate_ray<SLOTS>(sc, st, lane, alive, ps.bounces == 0, ps.o, ps.d, n_seg, n_mesh_seg, n_prim_mesh_seg, n_bvh_nodes, n_bvh_tests, cyc_mesh);
             PT_TICK(c2);
             const bool hit = h.id >= 0 && h.t < kInfinity;
-            n_hits += __popcll(__ballot(alive && hit && !fp.debug_normal));
+            n_hits += __popcll(wave_ballot(alive && hit && !fp.debug_normal));
             if (alive) {
                 bool done;
                 v3 colour;
@@ -717,8 +722,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     {
         for (;;) {
             // ---- refill dead lanes with the next pixels
-            unsigned long long dead = __ballot(state == S_DEAD);
-            if (more && dead && (__popcll(dead) >= fp.refill_min || !__any(state == S_FRESH || state == S_TRACE || state == S_READY))) {
+            unsigned long long dead = wave_ballot(state == S_DEAD);
+            if (more && dead && (__popcll(dead) >= fp.refill_min || !(wave_ballot(state == S_FRESH) | wave_ballot(state == S_TRACE) | wave_ballot(state == S_READY)))) {
                 while (dead) {
                     if (t_next >= t_valid) {
                         int item;
@@ -759,11 +764,12 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         state = S_FRESH;
                     }
                     t_next += min(n_dead, room);
-                    dead = __ballot(state == S_DEAD);
+                    dead = wave_ballot(state == S_DEAD);
                 }
             }
-            const unsigned long long m_mesh = __ballot(state == S_MESH);
-            const unsigned long long m_other = __ballot(state == S_FRESH || state == S_TRACE || state == S_READY);   // S_DIR never survives an iteration
+            const unsigned long long m_mesh = wave_ballot(state == S_MESH);
+            // one vote per comparison, combined as masks: a vote on a compound condition costs a v_cndmask + v_cmp pair extra
+            const unsigned long long m_other = wave_ballot(state == S_FRESH) | wave_ballot(state == S_TRACE) | wave_ballot(state == S_READY);   // S_DIR never survives an iteration
             if (!(m_mesh | m_other)) break;      // nothing alive and (refill ran) nothing left in the queue
             n_iter++;
             const int n_mesh = __popcll(m_mesh), n_other = __popcll(m_other);
@@ -776,9 +782,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
                 const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
                 for (;;) {
-                    const int n = __popcll(__ballot(state == S_MESH));
+                    const unsigned long long in_mesh = wave_ballot(state == S_MESH);
+                    const int n = __popcll(in_mesh);
                     if (n <= exit_at) break;
-                    const int n_node = __popcll(__ballot(state == S_MESH && cur >= 0));
+                    const int n_node = __popcll(in_mesh & wave_ballot(cur >= 0));
                     int next = 0;
                     bool moved = false, fin = false;       // lane got a new node/leaf code in `next`, or finished its ray
                     if (2 * n_node >= n) {
@@ -877,8 +884,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             PT_TICK(c1);
             PT_ACC(cyc_mesh, c0, c1);
             // ---- resolve phase (rt.comp:273-322), up to the point where a continuing path needs its random direction
-            if (__any(state == S_READY)) {
-                n_hits += __popcll(__ballot(state == S_READY && best_id >= 0 && best_t < kInfinity && !fp.debug_normal));
+            if (wave_any(state == S_READY)) {
+                if (!fp.debug_normal) n_hits += __popcll(wave_ballot(state == S_READY) & wave_ballot(best_id >= 0) & wave_ballot(best_t < kInfinity));
                 if (state == S_READY) {
                     Hit h;
                     h.id = best_id; h.t = best_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
@@ -943,8 +950,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             PT_ACC(cyc_shade, c1, c2);
             // ---- direction phase: RandomDirection (rt.comp:85-90) once for both of its callers -- the jitter of a new
             // primary ray (rt.comp:326-333) and the bounce direction of a continuing path (rt.comp:296-305)
-            if (__any(state == S_FRESH || state == S_DIR)) {
-                n_samples += __popcll(__ballot(state == S_FRESH));
+            if (wave_ballot(state == S_FRESH) | wave_ballot(state == S_DIR)) {
+                n_samples += __popcll(wave_ballot(state == S_FRESH));
                 if (state == S_FRESH || state == S_DIR) {
                     const bool fresh = state == S_FRESH;
                     if (fresh) ps.rng = (uint32_t)(fp.first_pass + k) * pix_seed;       // rt.comp:327
@@ -973,16 +980,16 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             PT_TICK(c3);
             PT_ACC(cyc_gen, c2, c3);
             // ---- trace phase: root-AABB gate (rt.comp:213) and scene primitives (rt.comp:219-230); the mesh is deferred
-            if (__any(state == S_TRACE)) {
+            if (wave_any(state == S_TRACE)) {
                 bool gate = false;
                 if (state == S_TRACE) {
                     if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
                     s_t = kInfinity; s_id = -1;
                     scene_closest(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
                 }
-                n_seg += __popcll(__ballot(state == S_TRACE));
-                n_mesh_seg += __popcll(__ballot(gate));
-                n_prim_mesh_seg += __popcll(__ballot(gate && ps.bounces == 0));
+                n_seg += __popcll(wave_ballot(state == S_TRACE));
+                n_mesh_seg += __popcll(wave_ballot(gate));
+                n_prim_mesh_seg += __popcll(wave_ballot(gate) & wave_ballot(ps.bounces == 0));
                 if (state == S_TRACE) {
                     if (gate || sph_root >= 0) {
                         // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
@@ -1083,7 +1090,7 @@ __global__ void __launch_bounds__(kWave) pt_tile_weights(SceneView sc, FramePara
             other = hit_sphere(V(sp.x, sp.y, sp.z), sp.w, o, d, t, front);
         }
     }
-    const unsigned w = 65u * __popcll(__ballot(gate)) + __popcll(__ballot(other && !gate));
+    const unsigned w = 65u * __popcll(wave_ballot(gate)) + __popcll(wave_ballot(other && !gate));
     if (lane == 0) fp.weights[tile] = w;
 }
 
