@@ -78,8 +78,10 @@ struct pt_ctx {
     float mesh_scale = 0.0f, sph_scale = 0.0f; int mesh_depth = 0, sph_depth = 0;
     bool bvh_ok = false;               // the traversal variants can run (something to traverse, nothing the builder refused in the mesh)
     float bvh_scale = 0.0f; int bvh_depth = 0, bvh_n_nodes = 0, sph_root = -1;
-    DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, mat_fres, counters;
+    DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, mat_fres, prim_tab, counters;
     int n_mesh = 0, n_chunks = 0, n_tris = 0, n_sph = 0, n_mats = 0;
+    std::vector<float4> h_mesh_rec, h_tri_rec;   // winner records (p1 | material, e1, e2, normal) of the mesh / the scene triangles
+    bool prim_dirty = true;                      // prim_tab = h_mesh_rec ++ h_tri_rec must be rebuilt
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
     bool have_mesh = false, have_scene = false, have_camera = false;
     uint32_t max_mat_mesh = 0, max_mat_scene = 0;   // largest material index referenced
@@ -151,7 +153,7 @@ SceneView scene_view(const pt_ctx *c)
     s.tri_e2 = (const float4 *)c->tri_e2.p; s.tri_nrm = (const float4 *)c->tri_nrm.p;
     s.n_tris = c->n_tris;
     s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
-    s.mats = (const PtMaterial *)c->mats.p; s.mat_fres = (const float4 *)c->mat_fres.p;
+    s.mats = (const PtMaterial *)c->mats.p; s.mat_fres = (const float4 *)c->mat_fres.p; s.prim_tab = (const float4 *)c->prim_tab.p;
     s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
     s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root;
     return s;
@@ -185,6 +187,15 @@ size_t bvh_lds_bytes(const pt_ctx *c)
 // Concatenate the two trees' nodes (mesh first: its root is node 0; the sphere tree's child indices are shifted) and upload.
 int sync_bvh(pt_ctx *c)
 {
+    if (c->prim_dirty) {
+        // one table of winner records indexed by canonical id (mesh triangles, then scene triangles): 64 B = one cache
+        // line per hit and ONE base pointer in the traversal kernels, where eight separate arrays cost 16 SGPRs
+        std::vector<float4> all(c->h_mesh_rec);
+        all.insert(all.end(), c->h_tri_rec.begin(), c->h_tri_rec.end());
+        HIPCHK(c, c->prim_tab.upload(all.data(), all.size() * sizeof(float4), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->prim_dirty = false;
+    }
     if (!c->nodes_dirty) return PT_OK;
     const bool mesh = c->n_mesh > 0 && c->mesh_bvh_ok, sph = c->n_sph > 0 && c->sph_bvh_ok;
     c->bvh_ok = (c->n_mesh == 0 || c->mesh_bvh_ok) && (mesh || sph);
@@ -380,7 +391,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->group_comm) (void)pt_group_finalize(c);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->mat_fres, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->mat_fres, &c->prim_tab, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
@@ -461,6 +472,9 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     HIPCHK(c, c->mesh_e1.upload(e1.data(), e1.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->mesh_e2.upload(e2.data(), e2.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->mesh_nrm.upload(nr.data(), nr.size() * sizeof(float4), c->stream));
+    c->h_mesh_rec.resize((size_t)4 * n);
+    for (int i = 0; i < n; i++) { c->h_mesh_rec[4 * (size_t)i] = p1[i]; c->h_mesh_rec[4 * (size_t)i + 1] = e1[i]; c->h_mesh_rec[4 * (size_t)i + 2] = e2[i]; c->h_mesh_rec[4 * (size_t)i + 3] = nr[i]; }
+    c->prim_dirty = true;
     // BVH for the traversal variant: leaf-ordered (p1 | original index, e1, e2) records + 64-byte nodes
     Bvh bvh;
     bool finite = true; float scale = 0.0f;
@@ -505,6 +519,9 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     std::vector<uint32_t> sm(n_sph);
     uint32_t maxm = 0;
     for (int i = 0; i < n_tris; i++) { tri_precompute(tris[i], p1[i], e1[i], e2[i], nr[i]); if (tris[i].materialIndex > maxm) maxm = tris[i].materialIndex; }
+    c->h_tri_rec.resize((size_t)4 * n_tris);
+    for (int i = 0; i < n_tris; i++) { c->h_tri_rec[4 * (size_t)i] = p1[i]; c->h_tri_rec[4 * (size_t)i + 1] = e1[i]; c->h_tri_rec[4 * (size_t)i + 2] = e2[i]; c->h_tri_rec[4 * (size_t)i + 3] = nr[i]; }
+    c->prim_dirty = true;
     for (int i = 0; i < n_sph; i++) {
         sp[i] = make_float4(sph[i].position[0], sph[i].position[1], sph[i].position[2], sph[i].radius);
         sm[i] = sph[i].materialIndex; if (sm[i] > maxm) maxm = sm[i];

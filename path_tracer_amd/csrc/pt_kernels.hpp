@@ -51,6 +51,7 @@ struct SceneView {
     const uint32_t *sph_mat;
     int n_sph;
     const PtMaterial *mats;   // SSBO 3
+    const float4 *prim_tab;   // [n_mesh + n_tris][4]: (p1 | material bits, e1, e2, normal) by canonical id -- the traversal kernels' only triangle table
     const float4 *mat_fres;   // per material, computed on the host with the same IEEE operations: 1/ior, r0 and n1/n2 of a front-face hit (pt_math.hpp fresnel_reflect_amount)
     // BVH over the mesh triangles (pt_bvh.hpp), used by the traversal variant
     const float4 *bvh_nodes;  // 4 x float4 per inner node: both child boxes + child codes
@@ -452,6 +453,49 @@ __device__ __forceinline__ void finish_hit(const SceneView &sc, v3 o, v3 d, Hit 
         } else {
             p1 = sc.mesh_p1[h.id]; e1 = sc.mesh_e1[h.id]; e2 = sc.mesh_e2[h.id]; nr = sc.mesh_nrm[h.id];
         }
+        float t, det;
+        hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        v3 n = V(nr.x, nr.y, nr.z);
+        h.front = !(det < 0.0f);                                        // rt.comp:174
+        h.normal = det < 0.0f ? n : -n;                                 // rt.comp:177
+        h.mat = __float_as_uint(p1.w);
+    }
+}
+
+// The same two steps for the traversal kernels, from the unified table (one base pointer, one cache line per record).
+__device__ __forceinline__ void scene_closest_tab(const SceneView &sc, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres)
+{
+    for (int i = 0; i < sc.n_tris; i++) {
+        const int rec = 4 * (sc.n_mesh + i);
+        const float4 p1 = uniform_load(sc.prim_tab, rec), e1 = uniform_load(sc.prim_tab, rec + 1), e2 = uniform_load(sc.prim_tab, rec + 2);
+        float t, det;
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
+    }
+    if (!with_spheres) return;
+    for (int i = 0; i < sc.n_sph; i++) {
+        const float4 s = uniform_load(sc.sph, i);
+        float t; bool front;
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
+    }
+}
+__device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, Hit &h)
+{
+    if (h.id < 0) return;
+    if (h.id >= sc.n_mesh + sc.n_tris) {
+        const int i = h.id - sc.n_mesh - sc.n_tris;
+        const float4 s = sc.sph[i];
+        float t; bool front;
+        hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        v3 point = o + d * h.t;                                         // rt.comp:144
+        v3 n = normalize(point - V(s.x, s.y, s.z));
+        h.front = front;
+        h.normal = front ? n : -n;                                      // rt.comp:147
+        h.mat = sc.sph_mat[i];
+    } else {
+        const float4 *r = sc.prim_tab + 4 * (size_t)h.id;
+        const float4 p1 = r[0], e1 = r[1], e2 = r[2], nr = r[3];
         float t, det;
         hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
         v3 n = V(nr.x, nr.y, nr.z);
@@ -889,7 +933,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 if (state == S_READY) {
                     Hit h;
                     h.id = best_id; h.t = best_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
-                    finish_hit(sc, ps.o, ps.d, h);
+                    finish_hit_tab(sc, ps.o, ps.d, h);
                     const bool hit = h.id >= 0 && h.t < kInfinity;
                     bool done = true;
                     v3 colour;
@@ -985,7 +1029,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 if (state == S_TRACE) {
                     if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
                     s_t = kInfinity; s_id = -1;
-                    scene_closest(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
+                    scene_closest_tab(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
                 }
                 n_seg += __popcll(wave_ballot(state == S_TRACE));
                 n_mesh_seg += __popcll(wave_ballot(gate));
