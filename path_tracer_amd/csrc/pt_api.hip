@@ -280,6 +280,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 8;
         fp.class_ppi[0] = fp.chunk; fp.class_ppi[1] = std::max(1, std::min(np, mul1 * fp.chunk)); fp.class_ppi[2] = std::max(1, std::min(np, mul2 * fp.chunk));
         if (fused) fp.class_ppi[0] = fp.class_ppi[1] = fp.class_ppi[2] = np;   // SHORT kernels: every item covers all passes
+        for (int k = 0; k < 3; k++) fp.per_tile[k] = (np + fp.class_ppi[k] - 1) / fp.class_ppi[k];
         // Scheduling of the traversal kernels' lane state machine, tuned on configs 2, 3, 5, 4K and the
         // short launches; the environment overrides them for experiments (0 / unset = these defaults).
         //   long launches: traverse at 32 parked lanes or after 4 iterations of waiting, leave the traversal phase with 3/8

@@ -80,6 +80,7 @@ struct FrameParams {
     const unsigned *order;    // [n_tiles] tile index by rank
     const int *class_count;   // [3] tiles per class: 0 = some pixel passes the mesh gate, 1 = hits only scene primitives, 2 = sky
     int class_ppi[3];         // passes per work item for each class
+    int per_tile[3];          // work items per tile for each class = ceil(n_passes / class_ppi) (host-computed)
     unsigned *weights;        // per-tile sort key, written by pt_tile_weights
     int park_high, park_wait; // BVH body: traverse when this many lanes are parked, or after this many iterations of waiting
     int refill_min;           // BVH body: hand out new pixels once this many lanes are idle
@@ -727,11 +728,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
     unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
     const unsigned long long t_start = wall_clock64();
-    const int count0 = fp.class_count[0], count1 = fp.class_count[1], count2 = fp.class_count[2];
-    const int per_tile0 = (fp.n_passes + fp.class_ppi[0] - 1) / fp.class_ppi[0], per_tile1 = (fp.n_passes + fp.class_ppi[1] - 1) / fp.class_ppi[1],
-              per_tile2 = (fp.n_passes + fp.class_ppi[2] - 1) / fp.class_ppi[2];
-    const int items0 = count0 * per_tile0, items1 = count1 * per_tile1;
-    const int n_items = items0 + items1 + count2 * per_tile2;
     unsigned *stk = st.stack;
     // Lanes are scheduled one by one: a lane that has finished its pixel takes the next unassigned pixel of the wave's
     // current work item (64 px of a row x a range of passes), and the wave fetches another item from the queue when that
@@ -781,11 +777,18 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
                             item = (int)__builtin_amdgcn_readfirstlane(fetched);
                         }
+                        // the class sizes are read here, per item, not kept in registers across the loop: a fetch is rare
+                        // (and costs a device-wide atomic anyway), while eight more live SGPRs spill in every iteration
+                        const volatile int *cc = fp.class_count;
+                        const int count0 = __builtin_amdgcn_readfirstlane(cc[0]), count1 = __builtin_amdgcn_readfirstlane(cc[1]),
+                                  count2 = __builtin_amdgcn_readfirstlane(cc[2]);
+                        const int items0 = count0 * fp.per_tile[0], items1 = count1 * fp.per_tile[1];
+                        const int n_items = items0 + items1 + count2 * fp.per_tile[2];
                         if (item >= n_items) { more = false; break; }
                         // item -> (class, tile rank, pass chunk): classes are contiguous in rank and in item index
                         int rel = item, rank0 = 0, cls = 0;
                         if (rel >= items0) { rel -= items0; rank0 = count0; cls = 1; if (rel >= items1) { rel -= items1; rank0 += count1; cls = 2; } }
-                        const int per_tile = cls == 0 ? per_tile0 : cls == 1 ? per_tile1 : per_tile2;
+                        const int per_tile = fp.per_tile[cls];
                         const int ppi = fp.class_ppi[cls];
                         const int chunk = rel % per_tile;
                         const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
