@@ -248,7 +248,9 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     const bool allow_fused = !(getenv("PT_NO_FUSED") && atoi(getenv("PT_NO_FUSED")));   // read per call: tests flip it
     const int variant0 = pick_variant(c);
     const bool fused = allow_fused && (variant0 == 5 || variant0 == 6) && n_passes <= c->chunk_passes;
-    const int batch = fused ? n_passes : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, c->workspace_limit / plane_bytes));
+    // the kernels index the workspace with 32 bits: passes in a batch x pixels < 2^32
+    const size_t batch_cap = std::min<size_t>(c->workspace_limit / plane_bytes, 0xffffffffull / ((size_t)c->width * c->height));
+    const int batch = fused ? n_passes : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, batch_cap));
     if (!fused && c->radiance.bytes < plane_bytes * batch) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->radiance.release();

@@ -723,7 +723,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
 {
     const int sph_root = SPH ? sc.sph_root : -1;
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
-    const size_t plane = (size_t)fp.width * fp.height;
+    const unsigned plane = (unsigned)(fp.width * fp.height);          // sample index k * plane + pixel < 2^32 (launch_trace bounds the batch)
     unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
     unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
     unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
@@ -983,7 +983,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             if (fp.sum_mode) acc = acc + colour;
                             else acc = mix3(acc, colour, exact_rcp((float)(fp.first_pass + k)));
                         } else {
-                            fp.radiance[(size_t)k * plane + (size_t)y * fp.width + x] = Rgb{colour.x, colour.y, colour.z};
+                            fp.radiance[(unsigned)k * plane + (unsigned)(y * fp.width + x)] = Rgb{colour.x, colour.y, colour.z};
                         }
                         k++;
                         state = k < k_end ? S_FRESH : S_DEAD;
