@@ -130,7 +130,8 @@ __device__ __forceinline__ float random_value_nd_generic(uint32_t &state)
 // u (profiles/nd_exact_mi355x.txt).
 __device__ __forceinline__ float nd_cos_of_draw(uint32_t r)
 {
-    const float a = kTwoPi * ((float)r / 4294967296.0f);
+    // kTwoPi * (r / 2^32): scaling by a power of two commutes with the rounding, so one multiply by kTwoPi * 2^-32 (exact)
+    const float a = (float)r * (kTwoPi * 2.3283064365386963e-10f);
     const float scale_y = a * (float)1.27323954473516;
     int32_t j = (int32_t)scale_y;
     j = (j + 1) & ~1;
@@ -156,9 +157,11 @@ __device__ __forceinline__ float nd_cos_of_draw(uint32_t r)
 }
 __device__ __forceinline__ float nd_rho_of_draw(uint32_t r)
 {
-    const float x = (float)r / 4294967296.0f;
-    const uint32_t u = __float_as_uint(x);
-    const float logexp = (float)((int32_t)(u >> 23) - 127);             // x >= 0: no sign bit to mask
+    // log(r / 2^32) from the bits of (float)r itself: same mantissa, exponent lower by 32.  r = 0 (log = -inf, rho = +inf)
+    // needs no test of its own: its exponent field 0 makes the argument of the square root 220, far above the 44.4 any
+    // other draw can reach, so it leaves through the range check of the short square root.
+    const uint32_t u = __float_as_uint((float)r);
+    const float logexp = (float)((int32_t)(u >> 23) - 159);
     const float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
     const float ya = m - 1.0f, yb = m + 1.0f;
     const float yr = __builtin_amdgcn_rcpf(yb);
@@ -170,9 +173,14 @@ __device__ __forceinline__ float nd_rho_of_draw(uint32_t r)
     const float z2 = z * z;
     const float even = fmaf(z2, fmaf(z2, c4, c2), c0);
     const float odd = fmaf(z2, c3, c1);
-    float res = fmaf(y, fmaf(odd, z, even), logexp);
-    if (x == 0.0f) res = -__builtin_inff();
-    return exact_sqrt(-2.0f * (res * (float)0.69314718055994529));
+    const float res = fmaf(y, fmaf(odd, z, even), logexp);
+    const float arg = -2.0f * (res * (float)0.69314718055994529);
+    // exact_sqrt's short form on [2^-64, 64); r = 0 and the draws that round to u = 1 (arg = -0) take the slow path
+    const float rs = __builtin_amdgcn_rsqf(arg);
+    const float sb = arg * rs;
+    float s = fmaf(fmaf(-sb, sb, arg), 0.5f * rs, sb);
+    if (__builtin_expect(!((__float_as_uint(arg) - 0x1f800000u) < (0x42800000u - 0x1f800000u)), 0)) s = r == 0u ? __builtin_inff() : sqrtf(arg);
+    return s;
 }
 __device__ __forceinline__ float random_value_nd(uint32_t &state)
 {
