@@ -59,6 +59,8 @@ typedef struct PtCounters {
     uint64_t bvh_node_visits;/* BVH variant: inner nodes fetched (two box tests each), per lane   */
     uint64_t bvh_tri_tests;  /* BVH variant: ray-triangle tests executed, per lane               */
     uint64_t phase_cycles[4];/* diagnostic builds (-DPT_PHASE_TIMERS=1): wave cycles in ray generation / closest hit / shading / (part of closest hit) mesh traversal; else 0 */
+    uint64_t bvh_sphere_tests;/* BVH variant: ray-sphere tests executed in sphere-tree leaves (not part of bvh_tri_tests) */
+    uint64_t bvh_box_tests;  /* BVH variant: ray-box (slab) tests executed: 2 per node visit of a binary node, 4 of a 4-wide one */
 } PtCounters;
 
 /* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */
@@ -147,14 +149,26 @@ int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
  * 5 = BVH traversal, one ray per lane, BVH in global memory (any mesh size), 6 = the same with the BVH staged into
  * LDS (default; falls back to 5 when nodes + triangles + stacks exceed 80 KB; see DESIGN.md for its exactness). */
 int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
+/* Scheduling options of the traversal kernels, per context, by name (experiments and tests; none changes a result, and
+ * the library reads no environment variable).  value 0 = the built-in choice for the launch at hand where noted.
+ *   "park_high" (0 | 1..64)  traverse when this many lanes of a wave are parked on the mesh
+ *   "park_wait" (0 | n)      ... or after this many iterations of waiting
+ *   "park_exit" (0 | 1..8)   leave the traversal phase with this many eighths of its rays unfinished
+ *   "refill_min" (0 | 1..64) hand out new pixels once this many lanes are idle
+ *   "ppi1_mul", "ppi2_mul"   passes per work item of scene-only / sky tiles, as multiples of the mesh tiles' (4, 8)
+ *   "no_fused" (0 | 1)       1: short launches also go through the per-pass workspace + pt_accumulate
+ * Unknown names and values out of range return PT_E_INVALID. */
+int pt_set_option(pt_ctx *ctx, const char *name, int value);
 /* Host-only (no HIP device needed; for tests and tools): build the library's BVH over `tris` exactly as pt_upload_mesh
  * does and verify it -- every triangle in exactly one leaf, every leaf of 1..8 triangles, every child box containing its
  * whole subtree, depth within the traversal stack.  Outputs (any may be NULL): inner nodes, depth, largest leaf, SAH cost
  * relative to the root box.  Returns PT_OK, PT_E_INVALID (bad arguments / non-finite coordinates, which pt_upload_mesh
  * answers by falling back to brute force) or PT_E_STATE (a check failed: a bug). */
 int pt_bvh_selftest(const PtTriangle *tris, int n_tris, int *n_nodes, int *depth, int *max_leaf, float *sah_cost);
-/* name of the dominant kernel symbol and its mesh-triangle slots per wave (for profiles/) */
+/* name of the library's default dominant kernel (for profiles/) */
 const char *pt_kernel_name(void);
+/* symbol (with template arguments) of the trace kernel the context's most recent render launched; "" before the first */
+const char *pt_last_kernel_name(const pt_ctx *ctx);
 int pt_version(void);
 
 #ifdef __cplusplus

@@ -22,8 +22,8 @@ SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
     "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
-    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
-    "pt_kernel_name",
+    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_set_option", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
+    "pt_kernel_name", "pt_last_kernel_name",
     "pt_version",
 ]
 
@@ -31,7 +31,8 @@ SYMBOLS = [
 class PtCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("mesh_segments", C.c_uint64), ("mesh_tri_tests", C.c_uint64), ("hits", C.c_uint64), ("wave_iterations", C.c_uint64),
                 ("primary_mesh_segments", C.c_uint64), ("waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64),
-                ("bvh_node_visits", C.c_uint64), ("bvh_tri_tests", C.c_uint64), ("phase_cycles", C.c_uint64 * 4)]
+                ("bvh_node_visits", C.c_uint64), ("bvh_tri_tests", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
+                ("bvh_sphere_tests", C.c_uint64), ("bvh_box_tests", C.c_uint64)]
 
 
 class PtError(RuntimeError):
@@ -105,12 +106,15 @@ def load():
     L.pt_reset_counters.argtypes = [vp]
     L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
     L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32, i32]
+    L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
     L.pt_bvh_selftest.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
     L.pt_group_unique_id.argtypes = [C.c_char_p]
     L.pt_group_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.pt_group_render.argtypes = [vp, i32, i32]
     L.pt_group_finalize.argtypes = [vp]
     L.pt_kernel_name.restype = C.c_char_p
+    L.pt_last_kernel_name.argtypes = [vp]
+    L.pt_last_kernel_name.restype = C.c_char_p
     L.pt_version.restype = i32
     _lib = L
     return L
@@ -240,6 +244,13 @@ class Renderer:
 
     def set_tuning(self, passes_per_item=0, workspace_limit_bytes=0, waves_per_cu=0, variant=0):
         self._ck(self.L.pt_set_tuning(self.h, passes_per_item, workspace_limit_bytes, waves_per_cu, variant))
+
+    def kernel_name(self):
+        """symbol of the trace kernel the most recent render launched (the library default before the first)"""
+        return self.L.pt_last_kernel_name(self.h).decode() or self.L.pt_kernel_name().decode()
+
+    def set_option(self, name, value):
+        self._ck(self.L.pt_set_option(self.h, name.encode(), int(value)))
 
 
 def bvh_selftest(tris):

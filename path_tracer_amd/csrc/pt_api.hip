@@ -54,6 +54,7 @@ struct pt_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<hipEvent_t> ev;        // pairs (before, after) around every pt_trace_items launch of the last render
     int n_timed = 0;
+    const char *last_kernel = "";      // symbol of the trace kernel the last render launched
     DevBuf radiance;                   // [batch passes][H][W] Rgb workspace (12 B per sample)
     size_t workspace_limit = (size_t)4 << 30;
     int chunk_passes = 4;              // passes per work item (mesh tiles; others take multiples)
@@ -88,9 +89,12 @@ struct pt_ctx {
 
     void *group_comm = nullptr;         // ncclComm_t of pt_group_init
     int group_rank = 0, group_world = 0;
+    int *group_agree = nullptr;         // device, kGroupAgree ints: the arguments every rank must share (pt_group_render)
     float cam[3] = {0, 0, 0}, iv[9] = {0};
     int max_bounces = 3;              // rt.comp:23
     int debug_normal = 0;
+    // scheduling options (pt_set_option; 0 = the built-in choice for the launch at hand)
+    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0;
 };
 
 namespace {
@@ -245,7 +249,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
     // running mean in registers: no per-pass workspace, no accumulate kernel.  Only for short pass ranges (interactive
     // use: one or a few passes per call): a lane task of 64 passes of a hard pixel runs for milliseconds and, started late,
     // becomes the tail of the launch (measured on config 2: 10.6 ms fused vs 7.8 ms with 4-pass items).
-    const bool allow_fused = !(getenv("PT_NO_FUSED") && atoi(getenv("PT_NO_FUSED")));   // read per call: tests flip it
+    const bool allow_fused = !c->opt_no_fused;
     const int variant0 = pick_variant(c);
     const bool fused = allow_fused && (variant0 == 5 || variant0 == 6) && n_passes <= c->chunk_passes;
     // the kernels index the workspace with 32 bits: passes in a batch x pixels < 2^32
@@ -279,17 +283,16 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         fp.queue = (unsigned *)c->queue.p; fp.n_tiles = n_tiles;
         // passes per work item: mesh tiles `chunk`; tiles that only bounce off scene primitives and sky tiles take more
         // passes per item (their items are short, and every item costs one ~11 ns device-wide atomic on the queue)
-        static const int mul1 = getenv("PT_PPI1_MUL") ? atoi(getenv("PT_PPI1_MUL")) : 4, mul2 = getenv("PT_PPI2_MUL") ? atoi(getenv("PT_PPI2_MUL")) : 8;
+        const int mul1 = c->opt_ppi1_mul, mul2 = c->opt_ppi2_mul;
         fp.class_ppi[0] = fp.chunk; fp.class_ppi[1] = std::max(1, std::min(np, mul1 * fp.chunk)); fp.class_ppi[2] = std::max(1, std::min(np, mul2 * fp.chunk));
         if (fused) fp.class_ppi[0] = fp.class_ppi[1] = fp.class_ppi[2] = np;   // SHORT kernels: every item covers all passes
         for (int k = 0; k < 3; k++) fp.per_tile[k] = (np + fp.class_ppi[k] - 1) / fp.class_ppi[k];
         // Scheduling of the traversal kernels' lane state machine, tuned on configs 2, 3, 5, 4K and the
-        // short launches; the environment overrides them for experiments (0 / unset = these defaults).
+        // short launches; pt_set_option overrides them per context for experiments (0 = these defaults).
         //   long launches: traverse at 32 parked lanes or after 4 iterations of waiting, leave the traversal phase with 3/8
         //   of its rays unfinished, refill at 4 idle lanes; short launches (tail-bound) and scenes with a sphere tree
         //   (every ray traverses) keep the earlier, more eager settings where those measured better.
-        static const int e_high = getenv("PT_PARK_HIGH") ? atoi(getenv("PT_PARK_HIGH")) : 0, e_wait = getenv("PT_PARK_WAIT") ? atoi(getenv("PT_PARK_WAIT")) : 0;
-        static const int e_refill = getenv("PT_REFILL_MIN") ? atoi(getenv("PT_REFILL_MIN")) : 0, e_exit = getenv("PT_PARK_EXIT") ? atoi(getenv("PT_PARK_EXIT")) : 0;
+        const int e_high = c->opt_park_high, e_wait = c->opt_park_wait, e_refill = c->opt_refill_min, e_exit = c->opt_park_exit;
         const bool big = variant0 == 5;       // BVH in global memory (large meshes: most rays traverse): larger batches
         fp.park_high = e_high ? e_high : (fused ? 40 : big ? 48 : 32);
         fp.park_wait = e_wait ? e_wait : (fused ? 2 : big ? 6 : 4);
@@ -309,12 +312,15 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         if (variant == 1) {
             const unsigned grid = (unsigned)std::min<long long>(items, (long long)c->n_cus * c->waves_per_cu);
             hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3(grid), dim3(kWave), 0, c->stream, sv, fp);
+            c->last_kernel = "pt_trace_items<11>";
         } else if (variant == 2) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 4);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 4>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+            c->last_kernel = "pt_trace_items_lds<11, 4>";
         } else if (variant == 3) {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 5);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+            c->last_kernel = "pt_trace_items_lds<11, 5>";
         } else if (variant == 6) {
             const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
             const size_t lds = bvh_lds_bytes(c);
@@ -324,6 +330,8 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
             int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + 1;
             void *args[] = {&sv, &fp, &n_nodes, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
+            c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh_lds<true, true>" : "pt_trace_items_bvh_lds<true, false>")
+                                              : (fused ? "pt_trace_items_bvh_lds<false, true>" : "pt_trace_items_bvh_lds<false, false>");
         } else if (variant == 5) {
             // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
             const size_t lds = (size_t)(c->bvh_depth + 1) * 4 * kLdsBlock;
@@ -334,9 +342,12 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
             int entries = c->bvh_depth + 1;
             void *args[] = {&sv, &fp, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kLdsBlock), args, lds, c->stream));
+            c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh<true, true>" : "pt_trace_items_bvh<true, false>")
+                                              : (fused ? "pt_trace_items_bvh<false, true>" : "pt_trace_items_bvh<false, false>");
         } else {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
+            c->last_kernel = "pt_trace_items_lds<11, 6>";
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
@@ -355,6 +366,8 @@ extern "C" {
 
 int pt_version(void) { return 1; }
 const char *pt_kernel_name(void) { return PT_DEFAULT_VARIANT >= 5 ? "pt_trace_items_bvh_lds" : "pt_trace_items_lds"; }
+
+const char *pt_last_kernel_name(const pt_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -396,6 +409,7 @@ void pt_destroy(pt_ctx *c)
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
                       &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->mat_fres, &c->prim_tab, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
+    if (c->group_agree) (void)hipFree(c->group_agree);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -507,6 +521,8 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     c->n_mesh = n; c->n_chunks = chunks; c->max_mat_mesh = maxm;
     for (int k = 0; k < 3; k++) { c->bmin[k] = n ? nodes[0].boundsMin[k] : 0.0f; c->bmax[k] = n ? nodes[0].boundsMax[k] : 0.0f; }
     c->have_mesh = true; c->order_dirty = true;
+    // tables the kernels read are brought up to date as soon as both halves of the scene are known
+    if (c->have_scene) return sync_bvh(c);
     return PT_OK;
 }
 
@@ -579,6 +595,7 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_tris = n_tris; c->n_sph = n_sph; c->n_mats = n_mats; c->max_mat_scene = maxm;
     c->have_scene = true; c->order_dirty = true;
+    if (c->have_mesh) return sync_bvh(c);
     return PT_OK;
 }
 
@@ -704,6 +721,7 @@ int pt_get_counters(pt_ctx *c, PtCounters *out)
     out->primary_mesh_segments = v[6]; out->waves = v[7]; out->wave_ticks_sum = v[8]; out->wave_ticks_max = v[9];
     out->bvh_node_visits = v[10]; out->bvh_tri_tests = v[11];
     out->phase_cycles[0] = v[12]; out->phase_cycles[1] = v[13]; out->phase_cycles[2] = v[14]; out->phase_cycles[3] = v[15];
+    out->bvh_sphere_tests = v[16]; out->bvh_box_tests = v[17];
     return PT_OK;
 }
 
@@ -740,6 +758,7 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
     int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
@@ -757,13 +776,15 @@ Rccl &rccl()
     r.GetUniqueId = (int (*)(Rccl::UniqueId *))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (int (*)(void **, int, Rccl::UniqueId, int))dlsym(h, "ncclCommInitRank");
     r.Reduce = (int (*)(const void *, void *, size_t, int, int, int, void *, hipStream_t))dlsym(h, "ncclReduce");
+    r.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
     r.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
     r.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.Reduce && r.CommDestroy && r.GetErrorString;
+    r.ok = r.GetUniqueId && r.CommInitRank && r.Reduce && r.AllReduce && r.CommDestroy && r.GetErrorString;
     if (!r.ok) r.why = "librccl.so lacks an expected symbol";
     return r;
 }
-constexpr int kNcclFloat32 = 7, kNcclSum = 0;                                   // rccl.h:448,466
+constexpr int kNcclFloat32 = 7, kNcclInt32 = 2, kNcclSum = 0, kNcclMax = 2;     // rccl.h ncclDataType_t / ncclRedOp_t
+constexpr int kGroupAgree = 13;            // six shared arguments as (x, -x) pairs + one status word
 }  // namespace
 }  // extern "C++"
 
@@ -792,6 +813,7 @@ int pt_group_init(pt_ctx *c, const char id[PT_GROUP_ID_BYTES], int rank, int wor
     const int rc = r.CommInitRank(&c->group_comm, world, u, rank);
     if (rc) { c->group_comm = nullptr; return fail(c, PT_E_HIP, "ncclCommInitRank: %s", r.GetErrorString(rc)); }
     c->group_rank = rank; c->group_world = world;
+    if (!c->group_agree) HIPCHK(c, hipMalloc((void **)&c->group_agree, kGroupAgree * sizeof(int)));
     return PT_OK;
 }
 
@@ -799,19 +821,45 @@ int pt_group_render(pt_ctx *c, int first_pass, int total_spp)
 {
     if (!c) return PT_E_INVALID;
     if (!c->group_comm) return fail(c, PT_E_STATE, "pt_group_init first");
-    if (first_pass < 1 || total_spp < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, total_spp);
-    int rc = check_ready(c);
-    if (rc) return rc;
     Bind b(c); HIPCHK(c, b.e);
+    Rccl &r = rccl();
+    // A collective must not be left by one rank alone: whatever is wrong locally (bad arguments, scene not uploaded) is
+    // first shared with the other ranks -- ONE all-reduce (max) of thirteen ints: the arguments every rank must agree on, each
+    // together with its negative (max of -x = -min of x), and this rank's local status -- and only then does anybody return.
+    int local = PT_OK;
+    if (first_pass < 1 || total_spp < 1) local = fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, total_spp);
+    if (local == PT_OK) local = check_ready(c);
+    const int mine[6] = {first_pass, total_spp, c->width, c->height, c->max_bounces, c->debug_normal};
+    int v[kGroupAgree] = {0};
+    for (int k = 0; k < 6; k++) { v[2 * k] = mine[k]; v[2 * k + 1] = -mine[k]; }
+    v[12] = -local;                                  // PT_E_* are negative: max over ranks of -status > 0 means some rank failed
+    HIPCHK(c, hipMemcpyAsync(c->group_agree, v, sizeof v, hipMemcpyHostToDevice, c->stream));
+    int nrc = r.AllReduce(c->group_agree, c->group_agree, kGroupAgree, kNcclInt32, kNcclMax, c->group_comm, c->stream);
+    if (nrc) return fail(c, PT_E_HIP, "ncclAllReduce: %s", r.GetErrorString(nrc));
+    int all[kGroupAgree];
+    HIPCHK(c, hipMemcpyAsync(all, c->group_agree, sizeof all, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (local != PT_OK) return local;                // this rank's own message is already set (the others leave two lines below)
+    if (all[12] > 0) return fail(c, PT_E_STATE, "another rank of the group failed its checks (status %d); nothing was rendered", -all[12]);
+    // every rank sees the same (max, min) pairs, so either all of them return here or none does
+    static const char *what[] = {"first_pass", "total_spp", "width", "height", "max_bounces", "debug_normal"};
+    for (int k = 0; k < 6; k++)
+        if (all[2 * k] != -all[2 * k + 1])
+            return fail(c, PT_E_INVALID, "the ranks of the group disagree on %s (here %d, over the group %d..%d); nothing was rendered", what[k], mine[k], -all[2 * k + 1], all[2 * k]);
     // contiguous, balanced split (the first total % world ranks take one pass more): path_tracer_amd/distributed.py pass_range
     const int base = total_spp / c->group_world, extra = total_spp % c->group_world;
     const int count = base + (c->group_rank < extra ? 1 : 0);
     const int first = first_pass + c->group_rank * base + std::min(c->group_rank, extra);
     const size_t n_floats = (size_t)c->width * c->height * 4;
     HIPCHK(c, hipMemsetAsync(c->accum, 0, n_floats * sizeof(float), c->stream));
-    if (count > 0 && (rc = launch_trace(c, first, count, 1)) != PT_OK) return rc;
-    Rccl &r = rccl();
-    const int nrc = r.Reduce(c->accum, c->accum, n_floats, kNcclFloat32, kNcclSum, 0, c->group_comm, c->stream);
+    int rc = PT_OK;
+    if (count > 0) rc = launch_trace(c, first, count, 1);
+    if (rc != PT_OK) {
+        // the peers are already on their way into the reduce: take part with an all-zero image, report the failure afterwards
+        (void)hipMemsetAsync(c->accum, 0, n_floats * sizeof(float), c->stream);
+    }
+    nrc = r.Reduce(c->accum, c->accum, n_floats, kNcclFloat32, kNcclSum, 0, c->group_comm, c->stream);
+    if (rc != PT_OK) return rc;
     if (nrc) return fail(c, PT_E_HIP, "ncclReduce: %s", r.GetErrorString(nrc));
     if (c->group_rank == 0) return pt_scale_accum(c, 1.0f / (float)total_spp, 1);
     return PT_OK;
@@ -884,6 +932,23 @@ int pt_bvh_selftest(const PtTriangle *tris, int n, int *n_nodes, int *depth, int
     if (max_leaf) *max_leaf = biggest;
     if (sah_cost) *sah_cost = root.half_area() > 0.0f ? (float)(cost / root.half_area()) : 0.0f;
     return PT_OK;
+}
+
+int pt_set_option(pt_ctx *c, const char *name, int value)
+{
+    if (!c || !name) return PT_E_INVALID;
+    struct { const char *name; int *slot; int lo, hi; } opts[] = {
+        {"park_high", &c->opt_park_high, 0, 64}, {"park_wait", &c->opt_park_wait, 0, 1 << 20}, {"refill_min", &c->opt_refill_min, 0, 64},
+        {"park_exit", &c->opt_park_exit, 0, 8}, {"ppi1_mul", &c->opt_ppi1_mul, 1, 4096}, {"ppi2_mul", &c->opt_ppi2_mul, 1, 4096},
+        {"no_fused", &c->opt_no_fused, 0, 1},
+    };
+    for (auto &o : opts)
+        if (!std::strcmp(name, o.name)) {
+            if (value < o.lo || value > o.hi) return fail(c, PT_E_INVALID, "option %s = %d outside [%d,%d]", name, value, o.lo, o.hi);
+            *o.slot = value;
+            return PT_OK;
+        }
+    return fail(c, PT_E_INVALID, "unknown option '%s'", name);
 }
 
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)

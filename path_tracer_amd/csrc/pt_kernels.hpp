@@ -33,7 +33,7 @@ namespace pt {
 #endif
 constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
-constexpr int kNumCounters = 16;
+constexpr int kNumCounters = 18;
 constexpr int kBvhStack = kBvhMaxDepth + 1;   // per-lane traversal stack entries (one extra: the sphere tree's root under the mesh tree)
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
@@ -88,6 +88,7 @@ struct FrameParams {
     int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
                                     // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span [10] BVH node visits [11] BVH triangle tests
+                                    // [12..15] phase cycles (diagnostic builds) [16] sphere tests in sphere-tree leaves [17] BVH box tests
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
 };
@@ -341,7 +342,14 @@ __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float
 }
 
 // The same test with the origin folded in: t = b * inv + (-(o +- delta) * inv), one FMA per plane, three-input min/max.
-// A ray that starts inside the grown box has t0 < 0 <= t1.  (inf - inf = NaN for an axis-parallel ray drops out as above.)
+// A ray that starts inside the grown box has t0 < 0 <= t1.  The folded form must never see an infinite `inv`: b * inf and
+// -(o * inf) are infinities of opposite sign for a box that straddles the origin's coordinate, and inf - inf = NaN on ONE
+// plane only would leave the other plane's infinity as a false "miss".  The caller therefore passes slab_inv(d), which is
+// 1/d limited to +-1e19: with |coordinates| < 1e18 (checked at upload) no product overflows, and shrinking |1/d| only
+// moves the slab's entry and exit towards t = 0 in proportion -- a ray that crawls along an axis at less than 1e-19 per
+// unit t cannot leave or enter the grown slab before t = 1e7 (kInfinity) unless it starts within 1e-12 of its surface,
+// and the box proper lies a full delta further in.
+__device__ __forceinline__ float slab_inv(float d) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d), -1e19f, 1e19f); }
 __device__ __forceinline__ void slab_test_fma(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 nlo, v3 nhi, v3 inv,
                                               float &t0, float &t1)
 {
@@ -725,7 +733,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const unsigned plane = (unsigned)(fp.width * fp.height);          // sample index k * plane + pixel < 2^32 (launch_trace bounds the batch)
     unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
-    unsigned n_bvh_nodes = 0, n_bvh_tests = 0;                          // per lane
+    unsigned n_bvh_nodes = 0, n_bvh_tests = 0, n_sph_tests = 0;         // per lane
     unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
     const unsigned long long t_start = wall_clock64();
     unsigned *stk = st.stack;
@@ -875,7 +883,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             float t; bool front;
                             const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front);
                             const int id = sc.n_mesh + sc.n_tris + si;
-                            n_bvh_tests++;
+                            n_sph_tests++;
                             if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
                             tri_pos++;
                             if (tri_pos == tri_end) {
@@ -1045,7 +1053,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         cur = gate ? 0 : sph_root;
                         if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
-                        inv = V(__builtin_amdgcn_rcpf(ps.d.x), __builtin_amdgcn_rcpf(ps.d.y), __builtin_amdgcn_rcpf(ps.d.z));
+                        inv = V(slab_inv(ps.d.x), slab_inv(ps.d.y), slab_inv(ps.d.z));
                         delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
                     } else {
                         state = S_READY;
@@ -1058,8 +1066,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
         }
     }
     if (fp.counters) {
-        for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); }
+        for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); if (SPH) n_sph_tests += __shfl_xor(n_sph_tests, off); }
         if (lane == 0) {
+            if (SPH) atomicAdd(&fp.counters[16], (unsigned long long)n_sph_tests);
+            atomicAdd(&fp.counters[17], 2ull * n_bvh_nodes);
             atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
             atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
             atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);

@@ -10,6 +10,8 @@
 //           [--group RANK WORLD IDFILE] one process per GPU (give each its --device): the --spp passes are split over the
 //                                      WORLD ranks, one RCCL reduce brings the sums to rank 0, which writes the outputs
 //                                      (pt_group_*, include/pt_hip.h); IDFILE is a path all ranks can reach
+//           [--handshake-only RANK WORLD IDFILE]  host-only: run just the id-file protocol of --group (GroupHandshake.h) with
+//                                      a stand-in id made on rank 0 and print the id every rank ends up with (tests)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +23,7 @@
 #include <utility>
 #include <vector>
 
+#include "GroupHandshake.h"
 #include "Renderer.h"
 
 using namespace ptm;
@@ -55,6 +58,7 @@ int main(int argc, char **argv)
     int orbit_frames = 0; float orbit_deg = 0.0f;
     std::vector<std::pair<std::string, int>> more_meshes;               // --add-mesh PATH MATERIAL (repeatable)
     int group_rank = 0, group_world = 0; std::string group_id_path;     // --group: one process per GPU, samples split over RCCL
+    bool handshake_only = false; double handshake_timeout = 60.0;
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (!std::strcmp(argv[i], "--mesh")) mesh_path = next();
@@ -72,6 +76,8 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--orbit")) { orbit_frames = std::atoi(next()); orbit_deg = std::strtof(next(), nullptr); }
         else if (!std::strcmp(argv[i], "--add-mesh")) { const char *p = next(); more_meshes.emplace_back(p, std::atoi(next())); }
         else if (!std::strcmp(argv[i], "--group")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); }
+        else if (!std::strcmp(argv[i], "--handshake-only")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); handshake_only = true; }
+        else if (!std::strcmp(argv[i], "--handshake-timeout")) handshake_timeout = std::strtod(next(), nullptr);
         else if (!std::strcmp(argv[i], "--cam")) { for (int k = 0; k < 5; k++) cam[k] = std::strtof(next(), nullptr); cam_given = true; }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -80,6 +86,17 @@ int main(int argc, char **argv)
         c.yaw = cam[3]; c.pitch = cam[4];
         c.UpdateView();
         for (int k = 0; k < 16; k++) { unsigned u; std::memcpy(&u, c.inverseView.data() + k, 4); std::printf("%08x%c", u, k == 15 ? '\n' : ' '); }
+        return 0;
+    }
+    if (group_world > 0 && (group_rank < 0 || group_rank >= group_world)) { std::fprintf(stderr, "bad rank %d of %d\n", group_rank, group_world); return 2; }
+    if (handshake_only) {   // no GPU: the stand-in id is 128 bytes derived from rank 0's nonce
+        char id[PT_GROUP_ID_BYTES];
+        auto make = [](char *out) { uint64_t x = handshake_nonce(); for (int k = 0; k < PT_GROUP_ID_BYTES; k++) { x = x * 6364136223846793005ull + 1442695040888963407ull; out[k] = (char)(x >> 56); } return true; };
+        if (!handshake_exchange(group_rank, group_world, group_id_path, id, sizeof id, make, handshake_timeout)) return 1;
+        handshake_cleanup(group_rank, group_id_path);
+        std::printf("rank %d id ", group_rank);
+        for (int k = 0; k < PT_GROUP_ID_BYTES; k++) std::printf("%02x", (unsigned char)id[k]);
+        std::printf("\n");
         return 0;
     }
     const bool mixed = scene_name == "mixed";
@@ -146,25 +163,13 @@ int main(int argc, char **argv)
                     dt * 1e3 / orbit_frames, orbit_frames / dt, Renderer::camera.position.x, Renderer::camera.position.y,
                     Renderer::camera.position.z, Renderer::camera.yaw);
     } else if (group_world > 0) {
-        // rank 0 makes the RCCL id and publishes it through a file (written aside, then renamed: never seen half-written)
+        // rank 0 makes the RCCL id; it travels through IDFILE (GroupHandshake.h: nonce-checked, so a file left by a run that
+        // died is never taken for this run's)
         char id[PT_GROUP_ID_BYTES];
-        if (group_rank == 0) {
-            if (!Renderer::Check(pt_group_unique_id(id), "pt_group_unique_id")) return 1;
-            const std::string tmp = group_id_path + ".tmp";
-            FILE *f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { std::perror(tmp.c_str()); return 1; }
-            std::fclose(f);
-            if (std::rename(tmp.c_str(), group_id_path.c_str())) { std::perror(group_id_path.c_str()); return 1; }
-        } else {
-            bool got = false;
-            for (int tries = 0; tries < 600 && !got; tries++) {        // up to 60 s for rank 0 to come up
-                FILE *f = std::fopen(group_id_path.c_str(), "rb");
-                if (f) { got = std::fread(id, 1, sizeof id, f) == sizeof id; std::fclose(f); }
-                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            }
-            if (!got) { std::fprintf(stderr, "no group id in %s after 60 s\n", group_id_path.c_str()); return 1; }
-        }
+        auto make = [](char *out) { return Renderer::Check(pt_group_unique_id(out), "pt_group_unique_id"); };
+        if (!handshake_exchange(group_rank, group_world, group_id_path, id, sizeof id, make, handshake_timeout)) return 1;
         if (!Renderer::Check(pt_group_init(Renderer::ctx, id, group_rank, group_world), "pt_group_init")) return 1;
+        handshake_cleanup(group_rank, group_id_path);
         if (!Renderer::Check(pt_group_render(Renderer::ctx, 1, spp), "pt_group_render")) return 1;
         if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
         if (!Renderer::Check(pt_group_finalize(Renderer::ctx), "pt_group_finalize")) return 1;

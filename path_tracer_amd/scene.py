@@ -284,3 +284,8 @@ def bench_camera() -> Camera:
 
 def mixed_camera() -> Camera:
     return Camera(position=np.array([1.5, 0.8, 1.5], f32), yaw=45.0, pitch=20.0).UpdateView()
+
+
+def heightfield_camera() -> Camera:
+    """Bench pose for config 3: above the height field, looking down at it (most primary rays traverse the mesh)."""
+    return Camera(position=np.array([0.2, 1.6, 2.2], f32), yaw=95.0, pitch=35.0).UpdateView()

@@ -125,6 +125,46 @@ def test_axis_parallel_rays_and_degenerate_triangles(capi):
     assert n_diff_pixels(ref, O.Oracle(sc, cam, W, H, B).render(1, SPP)) == 0
 
 
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_exactly_zero_direction_component_reaches_the_traversal(capi, axis):
+    """An inverseView whose row `axis` is all zeros makes EVERY primary ray's direction component on that axis exactly
+    (+-)0 (rt.comp:333 gives 0*X + 0 + 0*Y), with the camera inside that axis' slab of the mesh and of most BVH boxes: the
+    folded slab test of the traversal kernels sees 1/d = +-inf there (b*inf - o*inf = inf - inf on one plane only).  The
+    traversal must still return what the full scan and the oracle return."""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    sc = S.default_scene()
+    # a fan of rays in the plane {axis = const} through the bunny (bounds about [-0.24, 0.25] x [0, 0.49] x [-0.22, 0.17])
+    pos = {0: (0.011, 0.25, 1.2), 1: (1.2, 0.2, 0.013), 2: (1.2, 0.25, 0.017)}[axis]
+    cols = {0: [(0, 0, 0.9), (0, 1, 0), (0, -0.1, -1)],     # X sweeps z a little, Y sweeps y, forward -z
+            1: [(0, 0, 1), (0.4, 0, 0), (-1, 0, 0.02)],     # Y sweeps x, forward -x, all in the plane y = 0.2
+            2: [(0.3, 0, 0), (0, 1, 0), (-1, -0.05, 0)]}[axis]
+    cam = S.Camera(position=np.array(pos, np.float32), yaw=0.0, pitch=0.0).UpdateView()
+    iv = np.zeros((4, 4), np.float32)
+    for k in range(3):
+        iv[k, :3] = cols[k]
+    iv[3] = (*pos, 1.0)
+    assert np.all(iv[:3, axis] == 0.0)
+    cam.inverseView = iv
+    W, H, B, SPP = 128, 72, 4, 4
+    ref, c_ref = render(capi, sc, cam, W, H, B, SPP, 1)
+    assert c_ref["mesh_segments"] > 0.2 * c_ref["samples"]
+    ids = None
+    for variant in (5, 6):
+        img, c = render(capi, sc, cam, W, H, B, SPP, variant)
+        assert c["bvh_tri_tests"] > 0
+        assert bits_equal(img, ref), (axis, variant, n_diff_pixels(img, ref))
+    want = O.Oracle(sc, cam, W, H, B).render(1, SPP)
+    assert n_diff_pixels(ref, want) == 0
+    # the primary rays really have the exact zero, and a good share of them hit the mesh
+    r = capi.Renderer(W, H)
+    r.upload_scene(sc); r.SetUniformCamera(cam)
+    ids, _, dirs, _ = r.read_primary_hits(1)
+    r.close()
+    assert np.all(dirs[..., axis] == 0.0)
+    assert ((ids >= 0) & (ids < len(sc.mesh_tris))).mean() > 0.05
+
+
 def _same_or_both_nan(a, b):
     """bitwise equality, except that any NaN equals any NaN (x86 and gfx950 produce default NaNs of opposite sign)"""
     au, bu = a.view(np.uint32), b.view(np.uint32)

@@ -68,3 +68,40 @@ def test_group_bad_arguments(capi):
         with pytest.raises(capi.PtError):
             a.group_init(uid, rank, world)
     a.close()
+
+
+def test_group_render_reports_a_local_failure_after_the_agreement_round(capi, cameras, scenes):
+    """a rank whose scene is missing (or whose arguments are bad) must not leave the collective alone: the status travels
+    with the arguments in one all-reduce, then every rank returns an error (at world 1: this rank, without hanging)"""
+    a = capi.Renderer(64, 40)
+    a.group_init(capi.Renderer.group_unique_id(), 0, 1)
+    with pytest.raises(capi.PtError) as e:
+        a.group_render(1, 4)               # no scene uploaded
+    assert e.value.code == capi.PT_E_STATE
+    with pytest.raises(capi.PtError) as e:
+        a.group_render(0, 4)               # pass 0
+    assert e.value.code == capi.PT_E_INVALID
+    a.upload_scene(scenes["default"])
+    a.SetUniformCamera(cameras["bench"])
+    a.group_render(1, 4)                   # the communicator is still usable
+    assert np.all(a.read_accum()[:, :, 3] == 1.0)
+    a.group_finalize()
+    a.close()
+
+
+def test_bench_py_self_launches_two_ranks_in_rehearsal_mode():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the ranks before any GPU call.  On a one-GPU box
+    both ranks share cuda:0 and gloo stands in for RCCL (PT_BENCH_REHEARSAL=1): the N > 1 code path end to end, not a measurement"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PT_BENCH_REHEARSAL="1", GLOO_SOCKET_IFNAME="lo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 128 and "REHEARSAL" in d["data"]
+    assert d["value"] > 0 and d["roofline"]["work_per_launch"]["samples"] == 1920 * 1080 * 64

@@ -404,15 +404,15 @@ def test_config4_4k_sample_split_emulated_on_one_gpu(capi, cameras, scenes):
         np.testing.assert_allclose(got[y0:y0 + h, x0:x0 + w, :3], want[:, :, :3], rtol=1e-5, atol=1e-6)
 
 
-def test_fused_accumulation_equals_workspace_path(capi, cameras, scenes, monkeypatch):
-    """the traversal kernels keep the running mean in registers (one lane = all passes of a pixel); with PT_NO_FUSED=1
+def test_fused_accumulation_equals_workspace_path(capi, cameras, scenes):
+    """the traversal kernels keep the running mean in registers (one lane = all passes of a pixel); with option no_fused = 1
     they write per-pass radiance and pt_accumulate folds it: same image bit for bit, also when a render continues an
     earlier one (first_pass > 1) and in sum mode"""
     W, H = 160, 88
     imgs = {}
     for no_fused in ("0", "1"):
-        monkeypatch.setenv("PT_NO_FUSED", no_fused)
         r = make(capi, scenes["mixed"], cameras["mixed"], W, H, 6)
+        r.set_option("no_fused", int(no_fused))
         r.render(1, 5)
         r.render(6, 3)
         a = r.read_accum()

@@ -147,3 +147,51 @@ def test_cmake_build_produces_library_host_and_driver(tmp_path):
     args = [f"{v:.9g}" for v in e["position"]] + [f"{e['yaw']:.9g}", f"{e['pitch']:.9g}"]
     out = subprocess.run([str(b / "pt_main"), "--print-camera", "--cam", *args], check=True, capture_output=True, text=True).stdout.split()
     assert out == e["inverse_view_bits"]
+
+
+def _handshake(tmp_path, world, stale=(), delays=None, timeout="20"):
+    """run `pt_main --handshake-only` once per rank (host-only: returns before any GPU call) and collect the printed ids"""
+    import time
+    idfile = tmp_path / "group.id"
+    for name, content in stale:
+        (tmp_path / name).write_bytes(content)
+    procs = []
+    for rank in (delays or range(world)):
+        procs.append((rank, subprocess.Popen([PT_MAIN, "--handshake-only", str(rank), str(world), str(idfile), "--handshake-timeout", timeout],
+                                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        if delays:
+            time.sleep(0.3)
+    outs = {}
+    for rank, p in procs:
+        o, e = p.communicate(timeout=60)
+        outs[rank] = (p.returncode, o.strip(), e.strip())
+    return idfile, outs
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_group_id_file_handshake_world_n(tmp_path, world):
+    """the file protocol `pt_main --group` uses to hand the RCCL id from rank 0 to the others (host/GroupHandshake.h), run as
+    `world` real processes with a stand-in id: every rank ends up with rank 0's 128 bytes, nothing is left behind"""
+    idfile, outs = _handshake(tmp_path, world)
+    assert all(rc == 0 for rc, _, _ in outs.values()), outs
+    ids = {o.split(" id ")[1] for _, o, _ in outs.values()}
+    assert len(ids) == 1 and len(ids.pop()) == 256
+    assert sorted(os.listdir(tmp_path)) == [], os.listdir(tmp_path)
+
+
+def test_group_id_file_handshake_ignores_files_of_a_dead_run(tmp_path):
+    """an id file and request files left by a run that died must not be taken for this run's (a stale IDFILE made
+    ncclCommInitRank hang); the late starters go first so that rank 0 meets the stale request of rank 2 before the live one"""
+    stale = [("group.id", b"\xee" * (128 + 16)), ("group.id.req1", b"\x11" * 8), ("group.id.req2", b"\x22" * 8)]
+    idfile, outs = _handshake(tmp_path, 3, stale=stale, delays=[1, 0, 2])
+    assert all(rc == 0 for rc, _, _ in outs.values()), outs
+    ids = {o.split(" id ")[1] for _, o, _ in outs.values()}
+    assert len(ids) == 1 and ids.pop() != "ee" * 128
+    assert sorted(os.listdir(tmp_path)) == []
+
+
+def test_group_id_file_handshake_times_out_without_peers(tmp_path):
+    idfile, outs = _handshake(tmp_path, 2, delays=[1], timeout="1")
+    rc, _, err = outs[1]
+    assert rc != 0 and "no id for rank 1" in err
+    assert sorted(os.listdir(tmp_path)) == []

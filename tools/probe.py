@@ -17,6 +17,7 @@ ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="pt_set_option (repeatable), e.g. --opt park_high=48")
 a = ap.parse_args()
 import time
 if a.scene.startswith("hf"):
@@ -28,6 +29,8 @@ r = capi.Renderer(a.size[0], a.size[1])
 t0 = time.time(); r.upload_scene(sc); print("upload (incl. BVH build) %.2f s" % (time.time() - t0), flush=True); r.SetUniformCamera(cam); r.SetUniform1i("maxBounces", a.bounces)
 if a.chunk or a.waves or a.variant:
     r.set_tuning(a.chunk, 0, a.waves, a.variant)
+for kv in a.opt:
+    k, v = kv.split("="); r.set_option(k, int(v))
 ms = []
 for i in range(a.reps + 1):
     r.reset(); r.reset_counters(); r.render(1, a.spp); ms.append(r.last_render_ms())
