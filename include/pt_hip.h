@@ -100,6 +100,15 @@ int pt_render_pass(pt_ctx *ctx, int pass);
  * into a per-pass radiance workspace, then folded into the image in pass order; bit-identical to
  * calling pt_render_pass for each pass. */
 int pt_render(pt_ctx *ctx, int first_pass, int n_passes);
+/* pt_render for callers that cannot allocate (no counterpart in the reference): code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same arguments, same image bit for bit, but it calls no hipMalloc, hipFree or
+ * event/stream creation: the work-item queue, the tile schedule and the per-pass radiance workspace live in a 64 MiB array
+ * that is part of the library's code object (one copy per GPU, held until the process ends).  Limits: at most 65,536 tiles
+ * of 64 pixels (1920x1080 has 32,400); larger images return PT_E_LIMIT.  When the array holds fewer passes of the image than
+ * a launch is worth, the passes are taken in short launches that keep the running mean in registers (same result).  The
+ * scene must be uploaded before (uploads allocate).  All contexts on one GPU share that GPU's array: calls that overlap
+ * on one GPU race (serialise them, e.g. on one stream); pt_last_render_ms reports only renders of the allocating calls. */
+int pt_render_static(pt_ctx *ctx, int first_pass, int n_passes);
 /* Multi-GPU sample split (no reference counterpart; BASELINE.json north_star): adds the plain sum of
  * the 1-spp radiances of the given passes to the accumulation image (alpha += n_passes) so that
  * per-GPU buffers can be summed by an RCCL reduce; pt_scale_accum(1/spp) then yields the mean. */

@@ -20,7 +20,7 @@ PT_OK, PT_E_INVALID, PT_E_HIP, PT_E_STATE, PT_E_LIMIT = 0, -1, -2, -3, -4
 # every symbol include/pt_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
-    "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render",
+    "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render", "pt_render_static",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
     "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_set_option", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
     "pt_kernel_name", "pt_last_kernel_name",
@@ -94,6 +94,7 @@ def load():
     L.pt_set_max_bounces.argtypes = [vp, i32]
     L.pt_render_pass.argtypes = [vp, i32]
     L.pt_render.argtypes = [vp, i32, i32]
+    L.pt_render_static.argtypes = [vp, i32, i32]
     L.pt_render_sum.argtypes = [vp, i32, i32]
     L.pt_scale_accum.argtypes = [vp, C.c_float, i32]
     L.pt_reset.argtypes = [vp]
@@ -172,6 +173,9 @@ class Renderer:
 
     def render(self, first_pass, n_passes):
         self._ck(self.L.pt_render(self.h, first_pass, n_passes))
+
+    def render_static(self, first_pass, n_passes):
+        self._ck(self.L.pt_render_static(self.h, first_pass, n_passes))
 
     def render_sum(self, first_pass, n_passes):
         self._ck(self.L.pt_render_sum(self.h, first_pass, n_passes))

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <dlfcn.h>
@@ -26,9 +27,43 @@
 
 using namespace pt;
 
+// ---- pt_render_static's scratch: one array per GPU, in the code object itself -------------------------------------------
+// Everything pt_render keeps in buffers of its own beyond the caller's inputs and outputs -- the work-item queue, the tile
+// schedule (sort keys, order, class sizes) and the per-pass radiance workspace -- laid out in ONE file-scope device array, so
+// that pt_render_static never allocates.  Every GPU the library runs on holds its own copy (at its own address) until the
+// process ends.  In host code the array's NAME is only a stand-in: the device address comes from hipGetSymbolAddress, once
+// per device (scratch_base below, called by pt_create with that device current), and only that pointer is ever used.
+constexpr size_t kScratchBytes = (size_t)64 << 20;             // 64 MiB
+constexpr int kScratchMaxTiles = 1 << 16;                      // tiles of 64 px: 1920x1080 has 32,400, 2560x1440 57,600
+constexpr size_t kScratchQueueOff = 0, kScratchClassOff = 256, kScratchWeightsOff = 4096,
+                 kScratchOrderOff = kScratchWeightsOff + (size_t)kScratchMaxTiles * 4,
+                 kScratchRadianceOff = kScratchOrderOff + (size_t)kScratchMaxTiles * 4;       // 528,384: a multiple of 256
+static_assert(kScratchRadianceOff % 256 == 0 && kScratchRadianceOff < kScratchBytes, "scratch layout");
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// device address of `scratch` on `device` (which must be the current device); resolved once per device
+hipError_t scratch_base(int device, unsigned char **out)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        unsigned char *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct DevBuf {
     void *p = nullptr; size_t bytes = 0;
@@ -55,6 +90,7 @@ struct pt_ctx {
     std::vector<hipEvent_t> ev;        // pairs (before, after) around every pt_trace_items launch of the last render
     int n_timed = 0;
     const char *last_kernel = "";      // symbol of the trace kernel the last render launched
+    unsigned char *scratch_dev = nullptr;   // this device's copy of the static scratch array (pt_render_static)
     DevBuf radiance;                   // [batch passes][H][W] Rgb workspace (12 B per sample)
     size_t workspace_limit = (size_t)4 << 30;
     int chunk_passes = 4;              // passes per work item (mesh tiles; others take multiples)
@@ -237,50 +273,81 @@ int pick_variant(const pt_ctx *c)
     return variant;
 }
 
-int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
+// no_alloc (pt_render_static): queue, schedule and workspace live in the static scratch array; nothing is allocated, created or
+// freed on the way (no hipMalloc / hipFree / hipEventCreate), and sizes the array cannot hold are refused.
+int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_alloc = false)
 {
     int rc = check_ready(c);
     if (rc) return rc;
     if (first_pass < 0 || n_passes < 1) return fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, n_passes);
     Bind b(c); HIPCHK(c, b.e);
-    if ((rc = sync_bvh(c)) != PT_OK) return rc;
+    if (no_alloc && (c->prim_dirty || c->nodes_dirty)) return fail(c, PT_E_STATE, "scene tables not on the device yet (upload the mesh and the scene first)");
+    if (!no_alloc && (rc = sync_bvh(c)) != PT_OK) return rc;
     const size_t plane_bytes = (size_t)c->width * c->height * sizeof(Rgb);
+    const int n_tiles = (((c->width / 8) * 8 + kWave - 1) / kWave) * ((c->height / 8) * 8);
+    if (no_alloc) {
+        if (!c->scratch_dev) return fail(c, PT_E_STATE, "the static scratch array was not resolved on this device");
+        if (n_tiles > kScratchMaxTiles)
+            return fail(c, PT_E_LIMIT, "pt_render_static: %d x %d has %d tiles of 64 pixels, the static scratch holds %d (use pt_render)", c->width, c->height, n_tiles, kScratchMaxTiles);
+    }
     // The traversal kernels (variants 5, 6) schedule lane by lane, so one lane can take ALL passes of a pixel and keep the
     // running mean in registers: no per-pass workspace, no accumulate kernel.  Only for short pass ranges (interactive
     // use: one or a few passes per call): a lane task of 64 passes of a hard pixel runs for milliseconds and, started late,
     // becomes the tail of the launch (measured on config 2: 10.6 ms fused vs 7.8 ms with 4-pass items).
     const bool allow_fused = !c->opt_no_fused;
     const int variant0 = pick_variant(c);
-    const bool fused = allow_fused && (variant0 == 5 || variant0 == 6) && n_passes <= c->chunk_passes;
+    const bool can_fuse = allow_fused && (variant0 == 5 || variant0 == 6);
     // the kernels index the workspace with 32 bits: passes in a batch x pixels < 2^32
-    const size_t batch_cap = std::min<size_t>(c->workspace_limit / plane_bytes, 0xffffffffull / ((size_t)c->width * c->height));
-    const int batch = fused ? n_passes : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, batch_cap));
-    if (!fused && c->radiance.bytes < plane_bytes * batch) {
+    const size_t ws_limit = no_alloc ? kScratchBytes - kScratchRadianceOff : c->workspace_limit;
+    const size_t batch_cap = std::min<size_t>(ws_limit / plane_bytes, 0xffffffffull / ((size_t)c->width * c->height));
+    bool fused = can_fuse && n_passes <= c->chunk_passes;
+    int batch = fused ? n_passes : (int)std::max<size_t>(1, std::min<size_t>((size_t)n_passes, batch_cap));
+    if (no_alloc && !fused && batch_cap < (size_t)std::min(n_passes, c->chunk_passes + 1)) {
+        // the static workspace holds too few passes of this image to be worth a launch of its own: take the passes in short
+        // fused launches instead (bit-identical: the running mean continues in the image), or give up where those cannot run
+        if (!can_fuse) {
+            if (batch_cap < 1) return fail(c, PT_E_LIMIT, "pt_render_static: one pass of %d x %d needs %zu bytes of workspace, the static scratch has %zu (use pt_render)", c->width, c->height, plane_bytes, ws_limit);
+        } else {
+            fused = true; batch = c->chunk_passes;
+        }
+    }
+    if (!fused && !no_alloc && c->radiance.bytes < plane_bytes * batch) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->radiance.release();
         HIPCHK(c, hipMalloc(&c->radiance.p, plane_bytes * batch));
         c->radiance.bytes = plane_bytes * batch;
     }
     const int n_batches = (n_passes + batch - 1) / batch;
-    while ((int)c->ev.size() < 2 * n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev.push_back(e); }
+    const bool timed = !no_alloc || (int)c->ev.size() >= 2 * n_batches;     // events are created by the allocating path only
+    while (!no_alloc && (int)c->ev.size() < 2 * n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev.push_back(e); }
     SceneView sv = scene_view(c);
     c->n_timed = 0;
-    const int n_tiles = (((c->width / 8) * 8 + kWave - 1) / kWave) * ((c->height / 8) * 8);
-    if (c->tile_order.bytes < (size_t)n_tiles * sizeof(unsigned)) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->tile_weights.release(); c->tile_order.release();
-        HIPCHK(c, hipMalloc(&c->tile_weights.p, (size_t)n_tiles * sizeof(unsigned))); c->tile_weights.bytes = (size_t)n_tiles * sizeof(unsigned);
-        HIPCHK(c, hipMalloc(&c->tile_order.p, (size_t)n_tiles * sizeof(unsigned))); c->tile_order.bytes = (size_t)n_tiles * sizeof(unsigned);
-        if (!c->class_count.p) { HIPCHK(c, hipMalloc(&c->class_count.p, 4 * sizeof(int))); c->class_count.bytes = 4 * sizeof(int); }
-        c->order_dirty = true;
+    unsigned *q_ptr, *w_ptr, *o_ptr; int *cc_ptr; Rgb *rad_ptr;
+    if (no_alloc) {
+        q_ptr = (unsigned *)(c->scratch_dev + kScratchQueueOff); cc_ptr = (int *)(c->scratch_dev + kScratchClassOff);
+        w_ptr = (unsigned *)(c->scratch_dev + kScratchWeightsOff); o_ptr = (unsigned *)(c->scratch_dev + kScratchOrderOff);
+        rad_ptr = (Rgb *)(c->scratch_dev + kScratchRadianceOff);
+        c->order_dirty = true;      // the array is shared by every context on this GPU and keeps the last call's contents
+    } else {
+        if (c->tile_order.bytes < (size_t)n_tiles * sizeof(unsigned)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->tile_weights.release(); c->tile_order.release();
+            HIPCHK(c, hipMalloc(&c->tile_weights.p, (size_t)n_tiles * sizeof(unsigned))); c->tile_weights.bytes = (size_t)n_tiles * sizeof(unsigned);
+            HIPCHK(c, hipMalloc(&c->tile_order.p, (size_t)n_tiles * sizeof(unsigned))); c->tile_order.bytes = (size_t)n_tiles * sizeof(unsigned);
+            if (!c->class_count.p) { HIPCHK(c, hipMalloc(&c->class_count.p, 4 * sizeof(int))); c->class_count.bytes = 4 * sizeof(int); }
+            c->order_dirty = true;
+        }
+        q_ptr = (unsigned *)c->queue.p; cc_ptr = (int *)c->class_count.p;
+        w_ptr = (unsigned *)c->tile_weights.p; o_ptr = (unsigned *)c->tile_order.p; rad_ptr = (Rgb *)c->radiance.p;
     }
     for (int bi = 0; bi < n_batches; bi++) {
         const int p0 = first_pass + bi * batch, np = std::min(batch, n_passes - bi * batch);
         FrameParams fp = frame_params(c, p0, np, sum_mode);
+        fp.radiance = rad_ptr;
         // at most one item per (tile, pass): an upper bound for the grid and the 31-bit item index
         const long long items = (long long)n_tiles * ((np + fp.chunk - 1) / fp.chunk);
         if (items > 0x7fffffffll) return fail(c, PT_E_LIMIT, "too many work items in one batch (%lld); lower the workspace limit", items);
-        fp.queue = (unsigned *)c->queue.p; fp.n_tiles = n_tiles;
+        fp.queue = q_ptr; fp.n_tiles = n_tiles;
         // passes per work item: mesh tiles `chunk`; tiles that only bounce off scene primitives and sky tiles take more
         // passes per item (their items are short, and every item costs one ~11 ns device-wide atomic on the queue)
         const int mul1 = c->opt_ppi1_mul, mul2 = c->opt_ppi2_mul;
@@ -298,17 +365,17 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
         fp.park_wait = e_wait ? e_wait : (fused ? 2 : big ? 6 : 4);
         fp.refill_min = e_refill ? e_refill : (fused ? 8 : 4);
         fp.park_exit = e_exit ? e_exit : ((fused || c->sph_root >= 0) ? 2 : 3);
-        fp.weights = (unsigned *)c->tile_weights.p; fp.order = (const unsigned *)c->tile_order.p; fp.class_count = (const int *)c->class_count.p;
+        fp.weights = w_ptr; fp.order = o_ptr; fp.class_count = cc_ptr;
         if (c->order_dirty) {
             hipLaunchKernelGGL(pt_tile_weights, dim3((unsigned)n_tiles), dim3(kWave), 0, c->stream, sv, fp);
             HIPCHK(c, hipGetLastError());
-            hipLaunchKernelGGL(pt_sort_tiles, dim3(1), dim3(1024), 0, c->stream, fp.weights, (unsigned *)c->tile_order.p, (int *)c->class_count.p, n_tiles);
+            hipLaunchKernelGGL(pt_sort_tiles, dim3(1), dim3(1024), 0, c->stream, fp.weights, o_ptr, cc_ptr, n_tiles);
             HIPCHK(c, hipGetLastError());
             c->order_dirty = false;
         }
         const int variant = pick_variant(c);
-        HIPCHK(c, hipMemsetAsync(c->queue.p, 0, sizeof(unsigned), c->stream));
-        HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
+        HIPCHK(c, hipMemsetAsync(q_ptr, 0, sizeof(unsigned), c->stream));
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * bi], c->stream));
         if (variant == 1) {
             const unsigned grid = (unsigned)std::min<long long>(items, (long long)c->n_cus * c->waves_per_cu);
             hipLaunchKernelGGL(pt_trace_items<kSlots>, dim3(grid), dim3(kWave), 0, c->stream, sv, fp);
@@ -350,13 +417,14 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
             c->last_kernel = "pt_trace_items_lds<11, 6>";
         }
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
+        if (timed) HIPCHK(c, hipEventRecord(c->ev[2 * bi + 1], c->stream));
         if (!fused) {
             hipLaunchKernelGGL(pt_accumulate, dim3((fp.traced_width + 255) / 256, fp.rows), dim3(256), 0, c->stream, fp);
             HIPCHK(c, hipGetLastError());
         }
-        c->n_timed = bi + 1;
+        if (timed) c->n_timed = bi + 1;
     }
+    if (no_alloc) c->order_dirty = true;    // the next pt_render must not trust a schedule that lives in the shared array
     return PT_OK;
 }
 
@@ -387,6 +455,13 @@ int pt_create(pt_ctx **out, int device)
         return PT_E_HIP;
     }
     c->stream = c->own_stream;
+    // this device's copy of the static scratch array (pt_render_static): resolved here, once per device, with it current
+    if ((e = scratch_base(device, &c->scratch_dev)) != hipSuccess) {
+        fail(nullptr, PT_E_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return PT_E_HIP;
+    }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     unsigned long long zero[kNumCounters] = {0};
@@ -521,7 +596,8 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     c->n_mesh = n; c->n_chunks = chunks; c->max_mat_mesh = maxm;
     for (int k = 0; k < 3; k++) { c->bmin[k] = n ? nodes[0].boundsMin[k] : 0.0f; c->bmax[k] = n ? nodes[0].boundsMax[k] : 0.0f; }
     c->have_mesh = true; c->order_dirty = true;
-    // tables the kernels read are brought up to date as soon as both halves of the scene are known
+    // tables the kernels read are brought up to date as soon as both halves of the scene are known, so that a render
+    // (pt_render_static in particular) finds nothing left to upload
     if (c->have_scene) return sync_bvh(c);
     return PT_OK;
 }
@@ -631,6 +707,13 @@ int pt_render(pt_ctx *c, int first_pass, int n_passes)
     if (!c) return PT_E_INVALID;
     if (first_pass < 1) return fail(c, PT_E_INVALID, "currAccumPass starts at 1 (src/Main.cpp:144)");
     return launch_trace(c, first_pass, n_passes, 0);
+}
+
+int pt_render_static(pt_ctx *c, int first_pass, int n_passes)
+{
+    if (!c) return PT_E_INVALID;
+    if (first_pass < 1) return fail(c, PT_E_INVALID, "currAccumPass starts at 1 (src/Main.cpp:144)");
+    return launch_trace(c, first_pass, n_passes, 0, true);
 }
 
 int pt_render_sum(pt_ctx *c, int first_pass, int n_passes) { if (!c) return PT_E_INVALID; return launch_trace(c, first_pass, n_passes, 1); }
