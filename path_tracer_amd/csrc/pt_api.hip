@@ -130,7 +130,7 @@ struct pt_ctx {
     int max_bounces = 3;              // rt.comp:23
     int debug_normal = 0;
     // scheduling options (pt_set_option; 0 = the built-in choice for the launch at hand)
-    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0, opt_park_blocked = 0;
+    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0;
 };
 
 namespace {
@@ -269,8 +269,7 @@ int pick_variant(const pt_ctx *c)
     int variant = c->variant ? c->variant : PT_DEFAULT_VARIANT;
     if (variant >= 5 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
     if (variant == 6 && bvh_lds_bytes(c) > kBvhLdsLimit) variant = 5;     // too large for two workgroups per CU
-    if (variant >= 7 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;
-    if (variant == 7 && bvh_lds_bytes(c) > kBvhLdsLimit) variant = 8;
+
     if (variant >= 2 && variant <= 4 && c->n_chunks != 1) variant = 1;    // the LDS image holds exactly one chunk
     return variant;
 }
@@ -298,7 +297,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
     // becomes the tail of the launch (measured on config 2: 10.6 ms fused vs 7.8 ms with 4-pass items).
     const bool allow_fused = !c->opt_no_fused;
     const int variant0 = pick_variant(c);
-    const bool can_fuse = allow_fused && variant0 >= 5;
+    const bool can_fuse = allow_fused && (variant0 == 5 || variant0 == 6);
     // the kernels index the workspace with 32 bits: passes in a batch x pixels < 2^32
     const size_t ws_limit = no_alloc ? kScratchBytes - kScratchRadianceOff : c->workspace_limit;
     const size_t batch_cap = std::min<size_t>(ws_limit / plane_bytes, 0xffffffffull / ((size_t)c->width * c->height));
@@ -362,18 +361,12 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
         //   of its rays unfinished, refill at 4 idle lanes; short launches (tail-bound) and scenes with a sphere tree
         //   (every ray traverses) keep the earlier, more eager settings where those measured better.
         const int e_high = c->opt_park_high, e_wait = c->opt_park_wait, e_refill = c->opt_refill_min, e_exit = c->opt_park_exit;
-        const bool big = variant0 == 5 || variant0 == 8;       // BVH in global memory (large meshes: most rays traverse): larger batches
-        const bool dual = variant0 >= 7;
+        const bool big = variant0 == 5;       // BVH in global memory (large meshes: most rays traverse): larger batches
         fp.park_high = e_high ? e_high : (fused ? 40 : big ? 48 : 32);
         fp.park_wait = e_wait ? e_wait : (fused ? 2 : big ? 6 : 4);
         fp.refill_min = e_refill ? e_refill : (fused ? 8 : 4);
         fp.park_exit = e_exit ? e_exit : ((fused || c->sph_root >= 0) ? 2 : 3);
-        fp.park_blocked = c->opt_park_blocked ? c->opt_park_blocked : 16;
-        if (dual) {
-            // two paths per lane: the running paths do not wait for the parked ones, so the traversal can wait for a fuller wave
-            fp.park_high = e_high ? e_high : 48;
-            fp.park_wait = e_wait ? e_wait : 8;
-        }
+
         fp.weights = w_ptr; fp.order = o_ptr; fp.class_count = cc_ptr;
         if (c->order_dirty) {
             hipLaunchKernelGGL(pt_tile_weights, dim3((unsigned)n_tiles), dim3(kWave), 0, c->stream, sv, fp);
@@ -408,28 +401,6 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
             c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh_lds<true, true>" : "pt_trace_items_bvh_lds<true, false>")
                                               : (fused ? "pt_trace_items_bvh_lds<false, true>" : "pt_trace_items_bvh_lds<false, false>");
-        } else if (variant == 7) {
-            const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
-            const size_t lds = bvh_lds_bytes(c);
-            const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_dual_lds<true, true> : (const void *)&pt_trace_items_dual_lds<true, false>)
-                                                : (fused ? (const void *)&pt_trace_items_dual_lds<false, true> : (const void *)&pt_trace_items_dual_lds<false, false>);
-            HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + 1;
-            void *args[] = {&sv, &fp, &n_nodes, &entries};
-            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
-            c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_dual_lds<true, true>" : "pt_trace_items_dual_lds<true, false>")
-                                              : (fused ? "pt_trace_items_dual_lds<false, true>" : "pt_trace_items_dual_lds<false, false>");
-        } else if (variant == 8) {
-            const size_t lds = (size_t)(c->bvh_depth + 1) * 4 * kLdsBlock;
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));
-            const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * per_cu);
-            const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_dual<true, true> : (const void *)&pt_trace_items_dual<true, false>)
-                                                : (fused ? (const void *)&pt_trace_items_dual<false, true> : (const void *)&pt_trace_items_dual<false, false>);
-            int entries = c->bvh_depth + 1;
-            void *args[] = {&sv, &fp, &entries};
-            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kLdsBlock), args, lds, c->stream));
-            c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_dual<true, true>" : "pt_trace_items_dual<true, false>")
-                                              : (fused ? "pt_trace_items_dual<false, true>" : "pt_trace_items_dual<false, false>");
         } else if (variant == 5) {
             // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
             const size_t lds = (size_t)(c->bvh_depth + 1) * 4 * kLdsBlock;
@@ -1054,7 +1025,7 @@ int pt_set_option(pt_ctx *c, const char *name, int value)
     struct { const char *name; int *slot; int lo, hi; } opts[] = {
         {"park_high", &c->opt_park_high, 0, 64}, {"park_wait", &c->opt_park_wait, 0, 1 << 20}, {"refill_min", &c->opt_refill_min, 0, 64},
         {"park_exit", &c->opt_park_exit, 0, 8}, {"ppi1_mul", &c->opt_ppi1_mul, 1, 4096}, {"ppi2_mul", &c->opt_ppi2_mul, 1, 4096},
-        {"no_fused", &c->opt_no_fused, 0, 1}, {"park_blocked", &c->opt_park_blocked, 0, 64},
+        {"no_fused", &c->opt_no_fused, 0, 1},
     };
     for (auto &o : opts)
         if (!std::strcmp(name, o.name)) {
@@ -1068,7 +1039,7 @@ int pt_set_option(pt_ctx *c, const char *name, int value)
 int pt_set_tuning(pt_ctx *c, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant)
 {
     if (!c) return PT_E_INVALID;
-    if (variant < 0 || variant > 8) return fail(c, PT_E_INVALID, "variant outside [0,8]");
+    if (variant < 0 || variant > 6) return fail(c, PT_E_INVALID, "variant outside [0,6]");
     if (variant) c->variant = variant;
     if (waves_per_cu < 0 || waves_per_cu > 32) return fail(c, PT_E_INVALID, "waves_per_cu outside [1,32]");
     if (waves_per_cu) c->waves_per_cu = waves_per_cu;

@@ -85,7 +85,6 @@ struct FrameParams {
     int park_high, park_wait; // BVH body: traverse when this many lanes are parked, or after this many iterations of waiting
     int refill_min;           // BVH body: hand out new pixels once this many lanes are idle
     int park_exit;            // BVH body: leave the traversal phase when park_exit/8 of its rays are still unfinished
-    int park_blocked;         // dual-context body: traverse when this many lanes have BOTH contexts waiting for the mesh
     int n_tiles;
     unsigned long long *counters;   // [0] samples [1] segments [2] mesh segments [3] mesh tri tests [4] shaded hits [5] wave iterations
                                     // [6] primary mesh segments [7] waves [8] sum of wave spans (ticks) [9] longest wave span [10] BVH node visits [11] BVH triangle tests
@@ -1088,405 +1087,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Two paths per lane ("dual context"): the same state machine as trace_items_body_bvh, but a path that needs the mesh does
-// not park IN its lane -- it moves into the lane's second register set (the T context: whole path state + traversal state)
-// and the lane takes the next pixel at once.  So a wave carries up to 64 running paths (M contexts) AND up to 64 rays
-// waiting for / inside the traversal (T contexts): the per-lane phases no longer idle the lanes that wait for the mesh,
-// and the traversal phase starts with most lanes holding a ray instead of whatever fraction happened to be parked.
-//   M: FRESH -> TRACE -> READY -> DIR -> TRACE ... | PARK (wants the mesh; waits only while T is still busy)
-//   T: EMPTY -> MESH (traversing, resumable) -> DONE (closest hit known; waits for M to be free or to want T itself)
-// Exchange, once per iteration: PARK with T not busy, and DONE with M dead or parked, swap the two register sets (one
-// v_swap_b32 per register): the parked path starts its traversal, the finished one goes to the resolve phase.
-// Scheduling only, like everything here: a sample is a pure function of (pixel, pass).
-enum : int { T_EMPTY = 0, T_MESH = 1, T_DONE = 2, S_PARK = 6 };
-
-__device__ __forceinline__ void swap_f(float &a, float &b) { const float t = a; a = b; b = t; }
-__device__ __forceinline__ void swap_i(int &a, int &b) { const int t = a; a = b; b = t; }
-__device__ __forceinline__ void swap_u(uint32_t &a, uint32_t &b) { const uint32_t t = a; a = b; b = t; }
-__device__ __forceinline__ void swap_v(v3 &a, v3 &b) { swap_f(a.x, b.x); swap_f(a.y, b.y); swap_f(a.z, b.z); }
-
-template <bool SPH, bool SHORT, class Store>
-__device__ __forceinline__ void trace_items_body_dual(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
-{
-    const int sph_root = SPH ? sc.sph_root : -1;
-    const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
-    const unsigned plane = (unsigned)(fp.width * fp.height);          // sample index k * plane + pixel < 2^32 (launch_trace bounds the batch)
-    unsigned n_seg = 0, n_mesh_seg = 0, n_prim_mesh_seg = 0, n_hits = 0, n_samples = 0, n_iter = 0;
-    unsigned n_bvh_nodes = 0, n_bvh_tests = 0, n_sph_tests = 0;         // per lane
-    unsigned long long cyc_gen = 0, cyc_trace = 0, cyc_shade = 0, cyc_mesh = 0;
-    const unsigned long long t_start = wall_clock64();
-    unsigned *stk = st.stack;
-    int t_valid = 0, t_next = 0, t_x0 = 0, t_y = 0, t_k0 = 0, t_kend = 0;   // wave-uniform cursor into the current item
-    const int static_stride = (int)(gridDim.x * (blockDim.x / kWave));
-    int static_next = (int)(blockIdx.x + gridDim.x * (threadIdx.x / kWave));   // waves of one workgroup take items far apart in the list
-    bool more = true;                                                       // the queue may still hold items
-    // ---- M context: the path this lane is running
-    int x = 0, y = 0, k = 0, k_end = 0;                                     // pixel and pass range
-    v3 acc = V(0, 0, 0);                                                    // SHORT: running mean of the pixel (rt.comp:337-339)
-    float acc_w = 0.0f;
-    uint32_t pix_seed = 0;                                                  // pixelIndex (rt.comp:16); the rng seed is pass * pixelIndex
-    float pix_x = 0.0f, pix_y = 0.0f;                                       // pixelPos (rt.comp:14,17)
-    int state = S_DEAD;
-    PathState ps;
-    ps.o = ps.d = ps.ray_color = ps.incoming = ps.emitted = V(0, 0, 0); ps.rng = 0; ps.bounces = 0;
-    float s_t = kInfinity, best_t = kInfinity;                              // closest scene primitive (s_*); final closest hit (best_*)
-    int s_id = -1, best_id = -1;
-    bool park_gate = false;                                                 // S_PARK: the ray passed the root-AABB gate (rt.comp:213)
-    // a continuing path between the resolve and direction phases: hit point, normal, refraction index, mix weights
-    v3 hp = V(0, 0, 0), nrm = V(0, 0, 0);
-    float eta = 1.0f, mix_a = 0.0f, mix_b = 0.0f;
-    bool refr = false;
-    // ---- T context: the path whose ray is waiting for / inside the traversal (same fields, swapped with M as a block)
-    int q_x = 0, q_y = 0, q_k = 0, q_kend = 0;
-    v3 q_acc = V(0, 0, 0);
-    float q_accw = 0.0f;
-    uint32_t q_seed = 0;
-    float q_px = 0.0f, q_py = 0.0f;
-    int t_state = T_EMPTY;
-    PathState tp;
-    tp.o = tp.d = tp.ray_color = tp.incoming = tp.emitted = V(0, 0, 0); tp.rng = 0; tp.bounces = 0;
-    float q_st = kInfinity, q_best = kInfinity;
-    int q_sid = -1, q_bid = -1;
-    // resumable traversal state of T: cur >= 0 inner node to visit, cur < 0 inside a leaf at tri_pos .. tri_end
-    int cur = 0, sp = 0, tri_pos = 0, tri_end = 0;
-    bool leaf_sph = false;
-    v3 inv = V(0, 0, 0);
-    float delta = 0.0f;
-    int wait = 0;
-    for (;;) {
-        // ---- exchange M <-> T
-        {
-            const bool park = state == S_PARK, done = t_state == T_DONE;
-            const bool xchg = (park && t_state != T_MESH) || (done && state == S_DEAD);
-            if (wave_any(xchg)) {
-                if (xchg) {
-                    swap_v(ps.o, tp.o); swap_v(ps.d, tp.d); swap_v(ps.ray_color, tp.ray_color); swap_v(ps.incoming, tp.incoming); swap_v(ps.emitted, tp.emitted);
-                    swap_u(ps.rng, tp.rng); swap_i(ps.bounces, tp.bounces);
-                    swap_i(x, q_x); swap_i(y, q_y); swap_i(k, q_k); swap_i(k_end, q_kend);
-                    swap_u(pix_seed, q_seed); swap_f(pix_x, q_px); swap_f(pix_y, q_py);
-                    if (SHORT) { swap_v(acc, q_acc); swap_f(acc_w, q_accw); }
-                    swap_f(s_t, q_st); swap_i(s_id, q_sid); swap_f(best_t, q_best); swap_i(best_id, q_bid);
-                    state = done ? S_READY : S_DEAD;
-                    t_state = park ? T_MESH : T_EMPTY;
-                    if (park) {
-                        // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
-                        sp = 0; q_best = kInfinity; q_bid = -1;
-                        cur = park_gate ? 0 : sph_root;
-                        if (park_gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
-                        // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
-                        inv = V(slab_inv(tp.d.x), slab_inv(tp.d.y), slab_inv(tp.d.z));
-                        delta = 4e-6f * ((fabsf(tp.o.x) + fabsf(tp.o.y)) + (fabsf(tp.o.z) + sc.bvh_scale));
-                    }
-                }
-            }
-        }
-        // ---- refill dead lanes with the next pixels
-        unsigned long long dead = wave_ballot(state == S_DEAD);
-        if (more && dead && (__popcll(dead) >= fp.refill_min || !(wave_ballot(state == S_FRESH) | wave_ballot(state == S_TRACE) | wave_ballot(state == S_READY)))) {
-            while (dead) {
-                if (t_next >= t_valid) {
-                    int item;
-                    if (SHORT) {
-                        item = static_next; static_next += static_stride;
-                    } else {
-                        unsigned fetched = 0;
-                        if (lane == 0) fetched = atomicAdd(fp.queue, 1u);
-                        item = (int)__builtin_amdgcn_readfirstlane(fetched);
-                    }
-                    const volatile int *cc = fp.class_count;
-                    const int count0 = __builtin_amdgcn_readfirstlane(cc[0]), count1 = __builtin_amdgcn_readfirstlane(cc[1]),
-                              count2 = __builtin_amdgcn_readfirstlane(cc[2]);
-                    const int items0 = count0 * fp.per_tile[0], items1 = count1 * fp.per_tile[1];
-                    const int n_items = items0 + items1 + count2 * fp.per_tile[2];
-                    if (item >= n_items) { more = false; break; }
-                    int rel = item, rank0 = 0, cls = 0;
-                    if (rel >= items0) { rel -= items0; rank0 = count0; cls = 1; if (rel >= items1) { rel -= items1; rank0 += count1; cls = 2; } }
-                    const int per_tile = fp.per_tile[cls];
-                    const int ppi = fp.class_ppi[cls];
-                    const int chunk = rel % per_tile;
-                    const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
-                    t_x0 = (tile % fp.x_blocks) * kWave; t_y = tile / fp.x_blocks;
-                    t_k0 = chunk * ppi; t_kend = min(fp.n_passes, (chunk + 1) * ppi);
-                    t_valid = min(kWave, fp.traced_width - t_x0); t_next = 0;
-                }
-                const int n_dead = __popcll(dead), room = t_valid - t_next;
-                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dead, 0));   // dead lanes below this one
-                if (state == S_DEAD && rank < room) {
-                    x = t_x0 + t_next + rank; y = t_y; k = t_k0; k_end = t_kend;
-                    const float W = (float)fp.width, H = (float)fp.height;
-                    pix_seed = pixel_index(x, y, W, H);
-                    pix_x = ((((float)x / W) - 0.5f) * W) / H;      // rt.comp:14,17
-                    pix_y = ((float)y / H) - 0.5f;
-                    if (SHORT) {
-                        const float4 prev = reinterpret_cast<const float4 *>(fp.accum)[(size_t)y * fp.width + x];
-                        acc = V(prev.x, prev.y, prev.z); acc_w = prev.w;
-                    }
-                    state = S_FRESH;
-                }
-                t_next += min(n_dead, room);
-                dead = wave_ballot(state == S_DEAD);
-            }
-        }
-        const unsigned long long m_mesh = wave_ballot(t_state == T_MESH);
-        const unsigned long long m_other = wave_ballot(state == S_FRESH) | wave_ballot(state == S_TRACE) | wave_ballot(state == S_READY);   // S_DIR never survives an iteration
-        // after the exchange a parked M implies a traversing T, and a finished T implies a running M: nothing else can be left
-        if (!(m_mesh | m_other)) break;
-        n_iter++;
-        const int n_mesh = __popcll(m_mesh), n_other = __popcll(m_other);
-        const int n_blocked = __popcll(wave_ballot(state == S_PARK));
-        PT_TICK(c0);
-        if (n_mesh && (n_mesh >= fp.park_high || n_blocked >= fp.park_blocked || n_other == 0 || wait >= fp.park_wait)) {
-            // ---- traversal phase (T contexts)
-            wait = 0;
-            PT_COUNT(cyc_gen, 1); PT_COUNT(cyc_mesh, n_mesh);
-            const int exit_at = (n_other > 0 || n_blocked > 0) ? (n_mesh * fp.park_exit) >> 3 : 0;
-            const v3 nlo = V(-((tp.o.x + delta) * inv.x), -((tp.o.y + delta) * inv.y), -((tp.o.z + delta) * inv.z));
-            const v3 nhi = V(-((tp.o.x - delta) * inv.x), -((tp.o.y - delta) * inv.y), -((tp.o.z - delta) * inv.z));
-            for (;;) {
-                const unsigned long long in_mesh = wave_ballot(t_state == T_MESH);
-                const int n = __popcll(in_mesh);
-                if (n <= exit_at) break;
-                const int n_node = __popcll(in_mesh & wave_ballot(cur >= 0));
-                int next = 0;
-                bool moved = false, fin = false;       // lane got a new node/leaf code in `next`, or finished its ray
-                if (2 * n_node >= n) {
-                    PT_COUNT(cyc_trace, 1);
-                    if (t_state == T_MESH && cur >= 0) {
-                        float4 a, b, c;
-                        int kl, kr;
-                        st.node(cur, a, b, c, kl, kr);
-                        n_bvh_nodes++;
-                        float l0, l1, r0, r1;
-                        slab_test_fma(a.x, a.y, a.z, a.w, b.x, b.y, nlo, nhi, inv, l0, l1);
-                        slab_test_fma(b.z, b.w, c.x, c.y, c.z, c.w, nlo, nhi, inv, r0, r1);
-                        const float lim = fmaf(q_best, 1.001f, delta);
-                        // a sphere counts as hit down to t = -HIT_LIMIT (rt.comp:146), hence the slack on the far side
-                        const bool hl = l0 <= l1 && l1 >= -1e-4f && l0 <= lim, hr = r0 <= r1 && r1 >= -1e-4f && r0 <= lim;
-                        moved = true;
-                        if (hl && hr) {
-                            const bool left_first = l0 <= r0;
-                            next = left_first ? kl : kr;
-                            stk[sp * kWave] = (unsigned)(left_first ? kr : kl);
-                            sp++;
-                        } else if (hl) {
-                            next = kl;
-                        } else if (hr) {
-                            next = kr;
-                        } else if (sp == 0) {
-                            fin = true;
-                        } else {
-                            sp--;
-                            next = (int)stk[sp * kWave];
-                        }
-                    }
-                } else {
-                    PT_COUNT(cyc_shade, 1);
-                    if (SPH && t_state == T_MESH && cur < 0 && leaf_sph) {
-                        // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
-                        float4 cr;
-                        int si;
-                        st.sphere(tri_pos, cr, si);
-                        float t; bool front;
-                        const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, tp.o, tp.d, t, front);
-                        const int id = sc.n_mesh + sc.n_tris + si;
-                        n_sph_tests++;
-                        if (has && (t < q_best || (t == q_best && id < q_bid))) { q_best = t; q_bid = id; }
-                        tri_pos++;
-                        if (tri_pos == tri_end) {
-                            moved = true;
-                            if (sp == 0) fin = true;
-                            else { sp--; next = (int)stk[sp * kWave]; }
-                        }
-                    } else if (t_state == T_MESH && cur < 0) {
-                        // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
-                        const bool two = tri_pos + 1 < tri_end;
-                        float4 p1, e1, e2, q1, f1, f2;
-                        st.tri(tri_pos, p1, e1, e2);
-                        st.tri(two ? tri_pos + 1 : tri_pos, q1, f1, f2);
-                        float t, det, t2, det2;
-                        bool bad = false;
-                        bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), tp.o, tp.d, t, det, bad);
-                        bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), tp.o, tp.d, t2, det2, bad);
-                        if (__builtin_expect(bad, 0)) {
-                            has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), tp.o, tp.d, t, det);
-                            has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), tp.o, tp.d, t2, det2);
-                        }
-                        const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
-                        n_bvh_tests += two ? 2 : 1;
-                        if (has && (t < q_best || (t == q_best && id < q_bid))) { q_best = t; q_bid = id; }
-                        if (two && has2 && (t2 < q_best || (t2 == q_best && id2 < q_bid))) { q_best = t2; q_bid = id2; }
-                        tri_pos += two ? 2 : 1;
-                        if (tri_pos == tri_end) {
-                            moved = true;
-                            if (sp == 0) fin = true;
-                            else { sp--; next = (int)stk[sp * kWave]; }
-                        }
-                    }
-                }
-                if (moved) {
-                    if (fin) {
-                        // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
-                        // the lexicographic minimum of (t, canonical id)
-                        if (q_sid >= 0 && (q_st < q_best || (q_st == q_best && q_sid < q_bid))) { q_best = q_st; q_bid = q_sid; }
-                        t_state = T_DONE;
-                    } else if (next >= 0) {
-                        cur = next;
-                    } else {
-                        const int code = ~next;
-                        leaf_sph = SPH && (code & kSphereLeaf) != 0;
-                        tri_pos = (code & (kSphereLeaf - 1)) >> 3; tri_end = tri_pos + (code & 7) + 1;
-                        cur = -1;
-                    }
-                }
-            }
-        } else if (n_mesh) {
-            wait++;
-        }
-        PT_TICK(c1);
-        PT_ACC(cyc_mesh, c0, c1);
-        // ---- resolve phase (rt.comp:273-322), up to the point where a continuing path needs its random direction
-        if (wave_any(state == S_READY)) {
-            if (!fp.debug_normal) n_hits += __popcll(wave_ballot(state == S_READY) & wave_ballot(best_id >= 0) & wave_ballot(best_t < kInfinity));
-            if (state == S_READY) {
-                Hit h;
-                h.id = best_id; h.t = best_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
-                finish_hit_tab(sc, ps.o, ps.d, h);
-                const bool hit = h.id >= 0 && h.t < kInfinity;
-                bool done = true;
-                v3 colour;
-                if (hit && fp.debug_normal) {
-                    colour = h.normal;                              // rt.comp:274
-                } else {
-                    if (hit) {
-                        // rt.comp:276-311; the draws keep the shader's order: specular, refraction, then the direction
-                        ps.bounces++;
-                        const PtMaterial *m = &sc.mats[h.mat];
-                        const float m_ior = m->ior, m_smooth = m->smoothness;
-                        // FresnelReflectAmount(n1 = ior, n2 = m_ior) (rt.comp:235-254, :283): its two divisions and the 1/ior of
-                        // rt.comp:281 depend on the material only -- taken from the host's table (same IEEE operations)
-                        const float4 mf = sc.mat_fres[h.mat];
-                        const float ior = h.front ? mf.x : m_ior;
-                        const bool is_spec = m->specularChance > random_value(ps.rng);
-                        const float fres = fresnel_reflect_amount_pre(h.front ? mf.y : mf.w, ior > m_ior, mf.z, h.normal, ps.d, 1.0f - m->refractionAmount);
-                        const bool is_refr = fres < random_value(ps.rng);
-                        const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
-                        const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
-                        ps.emitted = ps.emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
-                        ps.ray_color = ps.ray_color * select3(is_refr, base, select3(is_spec, spec, base));
-                        ps.incoming = ps.incoming + ps.emitted * ps.ray_color;
-                        done = ps.bounces >= max_bounces;
-                        if (!done) {
-                            // the new direction (rt.comp:296-305) is finished in the direction phase; at the last
-                            // bounce the shader computes one too, but nothing reads it
-                            hp = ps.o + ps.d * h.t;                 // hitPoint (rt.comp:175 / :144)
-                            nrm = h.normal; eta = ior; refr = is_refr;
-                            mix_a = is_spec ? m->specularSmoothness : m_smooth; mix_b = m_smooth;
-                            state = S_DIR;
-                        }
-                    } else {
-                        ps.bounces++;
-                        ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);  // skyColor * skyIntensity (rt.comp:315)
-                        ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
-                    }
-                    const float nb = (float)ps.bounces;
-                    colour = div_small_int(ps.incoming, nb);   // rt.comp:322
-                }
-                if (done) {
-                    if (SHORT) {
-                        // rt.comp:337-339 in pass order, in registers: accum = mix(accum, colour, 1/pass)
-                        if (fp.sum_mode) acc = acc + colour;
-                        else acc = mix3(acc, colour, exact_rcp((float)(fp.first_pass + k)));
-                    } else {
-                        fp.radiance[(unsigned)k * plane + (unsigned)(y * fp.width + x)] = Rgb{colour.x, colour.y, colour.z};
-                    }
-                    k++;
-                    state = k < k_end ? S_FRESH : S_DEAD;
-                    if (SHORT && k == k_end)
-                        reinterpret_cast<float4 *>(fp.accum)[(size_t)y * fp.width + x] =
-                            make_float4(acc.x, acc.y, acc.z, fp.sum_mode ? acc_w + (float)fp.n_passes : 1.0f);
-                }
-            }
-        }
-        PT_TICK(c2);
-        PT_ACC(cyc_shade, c1, c2);
-        // ---- direction phase: RandomDirection (rt.comp:85-90) once for both of its callers -- the jitter of a new
-        // primary ray (rt.comp:326-333) and the bounce direction of a continuing path (rt.comp:296-305)
-        if (wave_ballot(state == S_FRESH) | wave_ballot(state == S_DIR)) {
-            n_samples += __popcll(wave_ballot(state == S_FRESH));
-            if (state == S_FRESH || state == S_DIR) {
-                const bool fresh = state == S_FRESH;
-                if (fresh) ps.rng = (uint32_t)(fp.first_pass + k) * pix_seed;       // rt.comp:327
-                const float gx = random_value_nd(ps.rng), gy = random_value_nd(ps.rng), gz = random_value_nd(ps.rng);
-                const v3 g = V(gx, gy, gz);
-                const float gr = exact_rcp(exact_sqrt(dot(g, g)));        // normalize(v) = v * (1/sqrt(dot(v,v)))
-                if (fresh) {
-                    // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
-                    const v3 jit = (g * 0.00025f) * gr;
-                    const float X = -pix_x + jit.x, Y = pix_y + jit.y;
-                    const float *m = fp.iv;
-                    ps.d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
-                    ps.o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
-                    ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
-                } else {
-                    const v3 r = g * gr;
-                    const v3 hemi = dot(r, nrm) > 0.0f ? r : -r;    // rt.comp:92-95
-                    const v3 a = mix3(hemi, reflect3(ps.d, nrm), mix_a);
-                    const v3 b = mix3(-hemi, refract3(ps.d, nrm, eta), mix_b);
-                    ps.d = normalize(select3(refr, b, a));
-                    ps.o = hp + ps.d * 0.0002f;                     // rt.comp:305
-                }
-                state = S_TRACE;
-            }
-        }
-        PT_TICK(c3);
-        PT_ACC(cyc_gen, c2, c3);
-        // ---- trace phase: root-AABB gate (rt.comp:213) and scene primitives (rt.comp:219-230); the mesh is deferred
-        if (wave_any(state == S_TRACE)) {
-            bool gate = false;
-            if (state == S_TRACE) {
-                if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
-                s_t = kInfinity; s_id = -1;
-                scene_closest_tab(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
-            }
-            n_seg += __popcll(wave_ballot(state == S_TRACE));
-            n_mesh_seg += __popcll(wave_ballot(gate));
-            n_prim_mesh_seg += __popcll(wave_ballot(gate) & wave_ballot(ps.bounces == 0));
-            if (state == S_TRACE) {
-                if (gate || sph_root >= 0) {
-                    state = S_PARK;                                 // moves into the T context at the next exchange
-                    park_gate = gate;
-                } else {
-                    state = S_READY;
-                    best_t = s_t; best_id = s_id;
-                }
-            }
-        }
-        PT_TICK(c4);
-        PT_ACC(cyc_trace, c3, c4);
-    }
-    if (fp.counters) {
-        for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); if (SPH) n_sph_tests += __shfl_xor(n_sph_tests, off); }
-        if (lane == 0) {
-            if (SPH) atomicAdd(&fp.counters[16], (unsigned long long)n_sph_tests);
-            atomicAdd(&fp.counters[17], 2ull * n_bvh_nodes);
-            atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
-            atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
-            atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
-            atomicAdd(&fp.counters[4], (unsigned long long)n_hits);
-            atomicAdd(&fp.counters[5], (unsigned long long)n_iter);
-            atomicAdd(&fp.counters[6], (unsigned long long)n_prim_mesh_seg);
-            atomicAdd(&fp.counters[10], (unsigned long long)n_bvh_nodes);
-            atomicAdd(&fp.counters[11], (unsigned long long)n_bvh_tests);
-            if (PT_PHASE_TIMERS) { atomicAdd(&fp.counters[12], cyc_gen); atomicAdd(&fp.counters[13], cyc_trace); atomicAdd(&fp.counters[14], cyc_shade); atomicAdd(&fp.counters[15], cyc_mesh); }
-            const unsigned long long span = wall_clock64() - t_start;
-            atomicAdd(&fp.counters[7], 1ull);
-            atomicAdd(&fp.counters[8], span);
-            atomicMax(&fp.counters[9], span);
-        }
-    }
-}
-
 // VGPR-resident triangles: persistent single-wave workgroups, 3 waves/SIMD (any mesh size).
 template <int SLOTS>
 __global__ void __launch_bounds__(kWave, 3) pt_trace_items(SceneView sc, FrameParams fp)
@@ -1623,35 +1223,6 @@ __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneV
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
     trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
-}
-
-// Dual-context variants (two paths per lane, trace_items_body_dual): same launch shapes and LDS layout as the two kernels above.
-template <bool SPH, bool SHORT>
-__global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_dual(SceneView sc, FrameParams fp, int stack_entries)
-{
-    extern __shared__ unsigned bvh_stack[];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    BvhStore st;
-    st.stack = bvh_stack + wave * (stack_entries * kWave) + lane;
-    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
-    trace_items_body_dual<SPH, SHORT>(sc, fp, st, lane);
-}
-template <bool SPH, bool SHORT>
-__global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_dual_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
-{
-    extern __shared__ float4 bvh_lds[];
-    const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh;
-    unsigned *stack = reinterpret_cast<unsigned *>(sph + n_sph_rec);
-    for (int i = threadIdx.x; i < 4 * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
-    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
-    for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
-    __syncthreads();
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    BvhLdsStore st;
-    st.stack = stack + wave * (stack_entries * kWave) + lane;
-    st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
-    trace_items_body_dual<SPH, SHORT>(sc, fp, st, lane);
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
