@@ -211,11 +211,16 @@ def main():
         # no launcher around us: start the ranks ourselves.  Nothing above has touched a GPU (no torch import, no HIP
         # call); the parent only waits for its children and passes rank 0's line through.
         from path_tracer_amd import launch
-        raise SystemExit(launch.launch(a.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]))
+        raise SystemExit(launch.launch(a.gpus, [sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
+                                       timeout_s=float(os.environ.get("PT_LAUNCH_TIMEOUT", "3000"))))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PT_BENCH_TRACEBACK_ON_TERM") == "1":     # a rank stopped by the launcher's time limit says where it was
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGTERM, all_threads=True, chain=True)
 
     import torch
     import torch.distributed as dist

@@ -10,6 +10,8 @@
 //           [--group RANK WORLD IDFILE] one process per GPU (give each its --device): the --spp passes are split over the
 //                                      WORLD ranks, one RCCL reduce brings the sums to rank 0, which writes the outputs
 //                                      (pt_group_*, include/pt_hip.h); IDFILE is a path all ranks can reach
+//           [--present-file ACCUM.f32 W H OUT.ppm]  host-only: the display step alone (ShaderProgram::WritePPM) on a raw
+//                                      RGBA32F image, row 0 = bottom row, as --out writes it
 //           [--handshake-only RANK WORLD IDFILE]  host-only: run just the id-file protocol of --group (GroupHandshake.h) with
 //                                      a stand-in id made on rank 0 and print the id every rank ends up with (tests)
 #include <chrono>
@@ -77,6 +79,15 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--add-mesh")) { const char *p = next(); more_meshes.emplace_back(p, std::atoi(next())); }
         else if (!std::strcmp(argv[i], "--group")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); }
         else if (!std::strcmp(argv[i], "--handshake-only")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); handshake_only = true; }
+        else if (!std::strcmp(argv[i], "--present-file")) {
+            const char *in = next(); const int w = std::atoi(next()), h = std::atoi(next()); const char *out = next();
+            if (w < 1 || h < 1) { std::fprintf(stderr, "bad size\n"); return 2; }
+            std::vector<float> img((size_t)w * h * 4);
+            FILE *f = std::fopen(in, "rb");
+            if (!f || std::fread(img.data(), sizeof(float), img.size(), f) != img.size()) { std::perror(in); return 1; }
+            std::fclose(f);
+            return ShaderProgram::WritePPM(img.data(), w, h, out) ? 0 : 1;
+        }
         else if (!std::strcmp(argv[i], "--handshake-timeout")) handshake_timeout = std::strtod(next(), nullptr);
         else if (!std::strcmp(argv[i], "--cam")) { for (int k = 0; k < 5; k++) cam[k] = std::strtof(next(), nullptr); cam_given = true; }
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }

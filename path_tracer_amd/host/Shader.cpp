@@ -31,20 +31,27 @@ static unsigned char srgb8(float v)
     return (unsigned char)std::lround(s * 255.0f);
 }
 
-bool ShaderProgram::Present(const char *ppmPath)
+// The display step of the reference: the accumulation texture is drawn 1:1 onto the window (compute_accum.frag:9-11) with
+// GL_FRAMEBUFFER_SRGB enabled (src/Renderer.cpp:135), i.e. clamp to [0,1], linear -> sRGB, 8 bits per channel; GL's texel
+// origin is the bottom-left corner, a PPM's first row is the top one.
+bool ShaderProgram::WritePPM(const float *rgba, int W, int H, const char *ppmPath)
 {
-    const int W = Renderer::screenWidth, H = Renderer::screenHeight;
-    std::vector<float> img((size_t)W * H * 4);
-    if (!Renderer::Check(pt_read_accum(Renderer::ctx, img.data(), img.size() * sizeof(float)), "pt_read_accum")) return false;
     FILE *f = std::fopen(ppmPath, "wb");
     if (!f) return false;
     std::fprintf(f, "P6\n%d %d\n255\n", W, H);
     std::vector<unsigned char> row((size_t)W * 3);
     for (int y = H - 1; y >= 0; y--) {      // image row 0 is the bottom row (GL texel origin)
         for (int x = 0; x < W; x++)
-            for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = srgb8(img[((size_t)y * W + x) * 4 + c]);
+            for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = srgb8(rgba[((size_t)y * W + x) * 4 + c]);
         std::fwrite(row.data(), 1, row.size(), f);
     }
-    std::fclose(f);
-    return true;
+    return std::fclose(f) == 0;
+}
+
+bool ShaderProgram::Present(const char *ppmPath)
+{
+    const int W = Renderer::screenWidth, H = Renderer::screenHeight;
+    std::vector<float> img((size_t)W * H * 4);
+    if (!Renderer::Check(pt_read_accum(Renderer::ctx, img.data(), img.size() * sizeof(float)), "pt_read_accum")) return false;
+    return WritePPM(img.data(), W, H, ppmPath);
 }

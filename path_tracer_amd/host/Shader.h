@@ -25,4 +25,6 @@ struct ShaderProgram {
     void Unuse() {}
     // GL_FRAMEBUFFER_SRGB + textured quad (src/Renderer.cpp:135, compute_accum.frag:9-11): write the image as 8-bit sRGB PPM
     bool Present(const char *ppmPath);
+    // the same transfer (clamp, linear -> sRGB, 8 bits, bottom row last) for an RGBA32F image already on the host
+    static bool WritePPM(const float *rgba, int width, int height, const char *ppmPath);
 };

@@ -329,6 +329,34 @@ def test_config3_1m_triangle_mesh_1080p_windows_vs_oracle(capi):
     a.close(); b.close()
 
 
+def test_config3_at_baseline_size_64spp_8_bounces(capi):
+    """BASELINE.json configs[2] at its full size -- 1,002,528 triangles, 1920x1080, 64 spp, 8 bounces -- rendered once:
+    sample and segment counters, run-to-run determinism (two renders, equal CRC), and two 24x4 windows compared bit for bit
+    with the brute-force oracle (2 x 96 px x 64 spp x ~2.3 segments x 1,002,528 triangle tests, tens of seconds of CPU)."""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    sc = S.default_scene(S.heightfield_mesh(708, 3))
+    cam = S.heightfield_camera()
+    W, H, B, SPP = 1920, 1080, 8, 64
+    r = make(capi, sc, cam, W, H, B)
+    r.reset_counters()
+    r.render(1, SPP)
+    full = r.read_accum()
+    c = r.counters()
+    assert c["samples"] == W * H * SPP and c["segments"] > 2 * c["samples"] and c["bvh_tri_tests"] > 0 and c["mesh_tri_tests"] == 0
+    assert c["bvh_tri_tests"] < 50 * c["mesh_segments"], "more than 50 of 1M triangles tested per ray"
+    assert r.kernel_name().startswith("pt_trace_items_bvh<")       # the BVH lives in global memory at this size
+    r.reset()
+    r.render(1, SPP)
+    assert crc(r.read_accum()) == crc(full)
+    assert np.all(full[:, :, 3] == 1.0) and np.isfinite(full).all()
+    r.close()
+    o = O.Oracle(sc, cam, W, H, B)
+    for (x0, y0, w, h) in ((940, 500, 24, 4), (300, 700, 24, 4)):
+        want = o.render_region(1, SPP, x0, y0, w, h)
+        assert n_diff_pixels(full[y0:y0 + h, x0:x0 + w], want) == 0, (x0, y0)
+
+
 @pytest.mark.parametrize("n_tris", [1, 3, 5])
 def test_bvh_tiny_meshes(capi, cameras, n_tris):
     """meshes at and below the leaf size (the BVH root is then a stand-in inner node over one leaf)"""
@@ -472,3 +500,4 @@ def test_ragged_image_sizes_vs_oracle(capi, cameras, scenes, size, spp):
     assert n_diff_pixels(got[:th, :tw], want[:th, :tw]) == 0
     assert np.all(got[th:, :, :] == 0) and np.all(got[:, tw:, :] == 0)
     r.close()
+

@@ -195,3 +195,49 @@ def test_group_id_file_handshake_times_out_without_peers(tmp_path):
     rc, _, err = outs[1]
     assert rc != 0 and "no id for rank 1" in err
     assert sorted(os.listdir(tmp_path)) == []
+
+
+def _srgb8_expected(v):
+    """GL_FRAMEBUFFER_SRGB's encoding (src/Renderer.cpp:135) in float64: clamp, linear -> sRGB, round to 8 bits; also returns
+    the distance of 255*s from the nearest rounding boundary, so that values a float32 evaluation may round the other way
+    can be left out of an exact comparison"""
+    v = np.clip(np.nan_to_num(np.asarray(v, np.float64), nan=0.0), 0.0, 1.0)
+    s = np.where(v <= 0.0031308, 12.92 * v, 1.055 * np.power(v, 1.0 / 2.4) - 0.055)
+    x = s * 255.0
+    return np.floor(x + 0.5).astype(np.int64), np.abs((x + 0.5) - np.round(x + 0.5))
+
+
+def test_present_values_follow_the_srgb_transfer_and_gl_row_order(tmp_path):
+    """the display step (ShaderProgram::WritePPM <- src/Renderer.cpp:135 GL_FRAMEBUFFER_SRGB + compute_accum.frag:9-11): exact
+    8-bit values for a ramp, out-of-range and non-finite inputs, alpha ignored, and image row 0 (GL's bottom row) written last"""
+    W, H = 256, 20
+    img = np.zeros((H, W, 4), np.float32)
+    ramp = (np.arange(W * (H - 4), dtype=np.float64) / (W * (H - 4) - 1)).astype(np.float32).reshape(H - 4, W)
+    img[:H - 4, :, 0] = ramp                            # full ramp 0..1, 4096 steps
+    img[:H - 4, :, 1] = ramp * np.float32(0.0031308 * 2)  # the linear segment and the knee
+    img[:H - 4, :, 2] = ramp ** 3                        # dense near black
+    img[H - 4, :, :3] = np.float32(-0.5)                 # below range -> 0
+    img[H - 3, :, :3] = np.float32(7.25)                 # above range -> 255
+    img[H - 2, :, 0], img[H - 2, :, 1], img[H - 2, :, 2] = np.float32("nan"), np.float32("inf"), np.float32("-inf")
+    img[H - 1, :, :3] = np.float32(0.5)                  # top row in GL terms
+    img[:, :, 3] = np.linspace(-3, 3, W, dtype=np.float32)[None, :]     # alpha must not matter
+    raw, ppm = tmp_path / "ramp.f32", tmp_path / "ramp.ppm"
+    img.tofile(raw)
+    subprocess.run([PT_MAIN, "--present-file", str(raw), str(W), str(H), str(ppm)], check=True, capture_output=True)
+    data = open(ppm, "rb").read()
+    header = b"P6\n%d %d\n255\n" % (W, H)
+    assert data.startswith(header) and len(data) == len(header) + W * H * 3
+    px = np.frombuffer(data[len(header):], np.uint8).reshape(H, W, 3)[::-1]          # back to GL row order
+    want, margin = _srgb8_expected(img[:, :, :3])
+    sure = margin > 1e-3                                  # 255*s at least 1e-3 away from x.5: no float32 evaluation rounds the other way
+    assert sure.mean() > 0.99
+    assert np.array_equal(px[sure], want[sure].astype(np.uint8))
+    assert np.all(np.abs(px.astype(int) - want) <= 1)
+    assert np.all(px[H - 4] == 0) and np.all(px[H - 3] == 255)
+    assert np.all(px[H - 2, :, 0] == 0) and np.all(px[H - 2, :, 1] == 255) and np.all(px[H - 2, :, 2] == 0)
+    assert np.all(px[H - 1] == 188)                      # 0.5 linear = 0.7354 sRGB = 187.5 -> 188 (255 * 0.73536 = 187.52)
+    # the file's FIRST row is GL's top row
+    first = np.frombuffer(data[len(header):len(header) + W * 3], np.uint8)
+    assert np.all(first == 188)
+    # anchors of the transfer function itself
+    assert _srgb8_expected(np.array([0.0, 1.0, 0.0031308, 0.2158605, 0.5]))[0].tolist() == [0, 255, 10, 128, 188]
