@@ -130,7 +130,7 @@ struct pt_ctx {
     int max_bounces = 3;              // rt.comp:23
     int debug_normal = 0;
     // scheduling options (pt_set_option; 0 = the built-in choice for the launch at hand)
-    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0;
+    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0, opt_wgs_per_cu = 0;
 };
 
 namespace {
@@ -217,11 +217,15 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     return f;
 }
 
+// Per-lane stack entries beyond the trees' depth: the permanent bottom entry, the other tree's root (counted in bvh_depth), and
+// the free slot above the stack that every node visit writes unconditionally.
+constexpr int kBvhStackExtra = 3;
 // LDS the LDS-resident BVH kernel needs per 512-thread workgroup; two workgroups must fit in a CU's 160 KB.
 constexpr size_t kBvhLdsLimit = 80 * 1024;
 size_t bvh_lds_bytes(const pt_ctx *c)
 {
-    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)(c->bvh_depth + 1) * 4 * kBvhLdsBlock;
+    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
+           + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * kBvhLdsBlock;
 }
 
 // Concatenate the two trees' nodes (mesh first: its root is node 0; the sphere tree's child indices are shifted) and upload.
@@ -391,24 +395,24 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
             c->last_kernel = "pt_trace_items_lds<11, 5>";
         } else if (variant == 6) {
-            const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * 2);
+            const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * (c->opt_wgs_per_cu ? c->opt_wgs_per_cu : 2));
             const size_t lds = bvh_lds_bytes(c);
             const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_bvh_lds<true, true> : (const void *)&pt_trace_items_bvh_lds<true, false>)
                                                 : (fused ? (const void *)&pt_trace_items_bvh_lds<false, true> : (const void *)&pt_trace_items_bvh_lds<false, false>);
             HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + 1;
+            int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + kBvhStackExtra;
             void *args[] = {&sv, &fp, &n_nodes, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
             c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh_lds<true, true>" : "pt_trace_items_bvh_lds<true, false>")
                                               : (fused ? "pt_trace_items_bvh_lds<false, true>" : "pt_trace_items_bvh_lds<false, false>");
         } else if (variant == 5) {
             // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
-            const size_t lds = (size_t)(c->bvh_depth + 1) * 4 * kLdsBlock;
+            const size_t lds = (size_t)kSceneLdsVecs * 16 + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * kLdsBlock;
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * per_cu);
             const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_bvh<true, true> : (const void *)&pt_trace_items_bvh<true, false>)
                                                 : (fused ? (const void *)&pt_trace_items_bvh<false, true> : (const void *)&pt_trace_items_bvh<false, false>);
-            int entries = c->bvh_depth + 1;
+            int entries = c->bvh_depth + kBvhStackExtra;
             void *args[] = {&sv, &fp, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kLdsBlock), args, lds, c->stream));
             c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh<true, true>" : "pt_trace_items_bvh<true, false>")
@@ -1025,7 +1029,7 @@ int pt_set_option(pt_ctx *c, const char *name, int value)
     struct { const char *name; int *slot; int lo, hi; } opts[] = {
         {"park_high", &c->opt_park_high, 0, 64}, {"park_wait", &c->opt_park_wait, 0, 1 << 20}, {"refill_min", &c->opt_refill_min, 0, 64},
         {"park_exit", &c->opt_park_exit, 0, 8}, {"ppi1_mul", &c->opt_ppi1_mul, 1, 4096}, {"ppi2_mul", &c->opt_ppi2_mul, 1, 4096},
-        {"no_fused", &c->opt_no_fused, 0, 1},
+        {"no_fused", &c->opt_no_fused, 0, 1}, {"wgs_per_cu", &c->opt_wgs_per_cu, 0, 8},
     };
     for (auto &o : opts)
         if (!std::strcmp(name, o.name)) {

@@ -149,6 +149,9 @@ __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_fl
 #define PT_TICK(var)
 #define PT_ACC(acc, a, b)
 #endif
+#ifndef PT_DUMMY_KIND
+#define PT_DUMMY_KIND 0
+#endif
 #ifndef PT_RAY_IN_VGPR
 #define PT_RAY_IN_VGPR 1
 #endif
@@ -304,6 +307,7 @@ struct BvhStore {
     }
     const float4 *sph;
     __device__ __forceinline__ void sphere(int j, float4 &cr, int &index) const { cr = sph[2 * j]; index = __float_as_int(sph[2 * j + 1].x); }
+    lds_cf4v *scene = nullptr;      // wave-uniform operands staged in LDS (stage_scene_lds), null: read through scalar loads
 };
 // ... or copied into the workgroup's LDS (meshes whose nodes + triangles fit beside the stacks): a dependent node
 // fetch then costs ~100 cycles instead of an L2 round trip, and the traversal is a chain of them.
@@ -327,6 +331,7 @@ struct BvhLdsStore {
     }
     lds_cf4v *sph;
     __device__ __forceinline__ void sphere(int j, float4 &cr, int &index) const { cr = f4(sph[2 * j]); index = __float_as_int(sph[2 * j + 1].x); }
+    lds_cf4v *scene = nullptr;      // wave-uniform operands staged in LDS (stage_scene_lds), null: read through scalar loads
 };
 
 __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 olo, v3 ohi, v3 inv,
@@ -707,6 +712,50 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 }
 
 
+// ---- wave-uniform operands through LDS ----------------------------------------------------------------------------------
+// On gfx950 a VALU instruction with an SGPR source issues in 4 SIMD cycles, the same instruction on VGPRs in 2
+// (profiles/valu_mix_mi355x.txt).  The scene triangles (SSBO 5), the root AABB and the camera are the same for every lane,
+// so the compiler keeps them in SGPRs (s_load) -- and every multiply, subtract and add of the per-lane phases that touches
+// them runs at half rate (27 of the 52 instructions of one scene-triangle test).  The traversal kernels therefore stage
+// these few values in LDS once per workgroup and read them back with ds_read_b128 at a wave-uniform address (a broadcast:
+// no bank conflict, no VALU slot): they arrive in VGPRs.  Layout (float4): [0, 3n) scene triangles (p1 | -, e1, e2),
+// then bmin, bmax, (iv0 iv1 iv2 iv3), (iv4 iv5 iv6 iv7), (iv8 cam.x cam.y cam.z).
+constexpr int kSceneLdsTris = 16;                                  // scenes with more triangles keep the scalar path
+constexpr int kSceneLdsVecs = 3 * kSceneLdsTris + 5;
+__device__ __forceinline__ bool stage_scene_lds(float4 *dst, const SceneView &sc, const FrameParams &fp, int tid, int n_threads)
+{
+    if (sc.n_tris > kSceneLdsTris) return false;
+    for (int i = tid; i < 3 * sc.n_tris; i += n_threads) dst[i] = sc.prim_tab[4 * (sc.n_mesh + i / 3) + i % 3];
+    if (tid == 0) {
+        float4 *c = dst + 3 * sc.n_tris;
+        c[0] = make_float4(sc.bmin[0], sc.bmin[1], sc.bmin[2], 0.0f);
+        c[1] = make_float4(sc.bmax[0], sc.bmax[1], sc.bmax[2], 0.0f);
+        c[2] = make_float4(fp.iv[0], fp.iv[1], fp.iv[2], fp.iv[3]);
+        c[3] = make_float4(fp.iv[4], fp.iv[5], fp.iv[6], fp.iv[7]);
+        c[4] = make_float4(fp.iv[8], fp.cam[0], fp.cam[1], fp.cam[2]);
+    }
+    return true;
+}
+__device__ __forceinline__ float4 lds_f4(lds_cf4v *p, int i) { const f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+
+// scene_closest_tab with the triangle records read from the LDS copy (VGPR operands); spheres as before
+__device__ __forceinline__ void scene_closest_lds(const SceneView &sc, lds_cf4v *scene, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres)
+{
+    for (int i = 0; i < sc.n_tris; i++) {
+        const float4 p1 = lds_f4(scene, 3 * i), e1 = lds_f4(scene, 3 * i + 1), e2 = lds_f4(scene, 3 * i + 2);
+        float t, det;
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
+    }
+    if (!with_spheres) return;
+    for (int i = 0; i < sc.n_sph; i++) {
+        const float4 s = uniform_load(sc.sph, i);
+        float t; bool front;
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BVH body: the same persistent waves, work items and persistent lanes as trace_items_body, but a lane's path is a
 // small state machine so that rays which need the mesh can WAIT for each other:
@@ -722,6 +771,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 // Scheduling only: a sample is a pure function of (pixel, pass); mesh-before-scene tie order is kept by the merge rule
 // in `finish`: a scene primitive wins only with a strictly smaller t (rt.comp:213-230 scans the mesh first).
 enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DIR = 5 };
+constexpr int kTravDone = (int)0x80000000;      // traversal position of a lane that is not traversing; also the bottom of every stack
 
 // SPH: the scene has a sphere tree (compile-time, so scenes without spheres carry none of its code or registers).
 // SHORT: launches of a few passes (interactive use): items are dealt round-robin to the waves instead of pulled from the
@@ -761,9 +811,9 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     // closest hit: scene primitives (s_t, s_id); mesh traversal / final result (best_t, best_id)
     float s_t = kInfinity, best_t = kInfinity;
     int s_id = -1, best_id = -1;
-    // resumable traversal state: cur >= 0 inner node to visit, cur < 0 inside a leaf at tri_pos .. tri_end
-    int cur = 0, sp = 0, tri_pos = 0, tri_end = 0;
-    bool leaf_sph = false;
+    // resumable traversal state (see the traversal phase): position `cur`, stack height `sp` (slot 0 = kTravDone for good)
+    int cur = kTravDone, sp = 1;
+    stk[0] = (unsigned)kTravDone;
     v3 inv = V(0, 0, 0);
     float delta = 0.0f;
     int wait = 0;
@@ -830,25 +880,31 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             const int n_mesh = __popcll(m_mesh), n_other = __popcll(m_other);
             PT_TICK(c0);
             if (n_mesh && (n_mesh >= fp.park_high || n_other == 0 || wait >= fp.park_wait)) {
-                // ---- traversal phase
+                // ---- traversal phase.  A lane's whole position is ONE register: cur >= 0 inner node to visit; cur < 0 the code
+                // of the leaf it is in (~cur = flag | first << 3 | count - 1, rewritten as its primitives are used up); cur ==
+                // kTravDone not traversing.  Slot 0 of every lane's stack holds kTravDone for good, so "pop" needs no empty test,
+                // and both kinds of step read the top of the stack speculatively together with their node / primitive data.
+                // The step bodies are written without branches (selects, one unconditional store to the free slot above the
+                // stack): on this kernel a scalar instruction costs as much issue time as a vector one (profiles/insitu_cost_*),
+                // and the nest of exec-mask branches this replaces was 45 of them per node visit.
                 wait = 0;
                 PT_COUNT(cyc_gen, 1); PT_COUNT(cyc_mesh, n_mesh);
                 const int exit_at = n_other > 0 ? (n_mesh * fp.park_exit) >> 3 : 0;
                 const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
                 const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
                 for (;;) {
-                    const unsigned long long in_mesh = wave_ballot(state == S_MESH);
+                    const unsigned long long in_mesh = wave_ballot(cur != kTravDone);
                     const int n = __popcll(in_mesh);
                     if (n <= exit_at) break;
-                    const int n_node = __popcll(in_mesh & wave_ballot(cur >= 0));
-                    int next = 0;
-                    bool moved = false, fin = false;       // lane got a new node/leaf code in `next`, or finished its ray
+                    const int n_node = __popcll(wave_ballot(cur >= 0));
+                    int new_cur = cur;                     // lanes of the other kind keep their position
                     if (2 * n_node >= n) {
                         PT_COUNT(cyc_trace, 1);
-                        if (state == S_MESH && cur >= 0) {
+                        if (cur >= 0) {
                             float4 a, b, c;
                             int kl, kr;
                             st.node(cur, a, b, c, kl, kr);
+                            const int top = (int)stk[(sp - 1) * kWave];
                             n_bvh_nodes++;
                             float l0, l1, r0, r1;
                             slab_test_fma(a.x, a.y, a.z, a.w, b.x, b.y, nlo, nhi, inv, l0, l1);
@@ -856,80 +912,65 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             const float lim = fmaf(best_t, 1.001f, delta);
                             // a sphere counts as hit down to t = -HIT_LIMIT (rt.comp:146), hence the slack on the far side
                             const bool hl = l0 <= l1 && l1 >= -1e-4f && l0 <= lim, hr = r0 <= r1 && r1 >= -1e-4f && r0 <= lim;
-                            moved = true;
-                            if (hl && hr) {
-                                const bool left_first = l0 <= r0;
-                                next = left_first ? kl : kr;
-                                stk[sp * kWave] = (unsigned)(left_first ? kr : kl);
-                                sp++;
-                            } else if (hl) {
-                                next = kl;
-                            } else if (hr) {
-                                next = kr;
-                            } else if (sp == 0) {
-                                fin = true;
-                            } else {
-                                sp--;
-                                next = (int)stk[sp * kWave];
-                            }
+                            const bool take_left = hl && (!hr || l0 <= r0);
+                            const int near = take_left ? kl : kr, far = take_left ? kr : kl;
+                            stk[sp * kWave] = (unsigned)far;            // stays on the stack only if both children are hit
+                            const bool both = hl && hr, any = hl || hr;
+                            new_cur = any ? near : top;
+                            sp += both ? 1 : (any ? 0 : -1);
                         }
                     } else {
                         PT_COUNT(cyc_shade, 1);
-                        if (SPH && state == S_MESH && cur < 0 && leaf_sph) {
-                            // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
-                            float4 cr;
-                            int si;
-                            st.sphere(tri_pos, cr, si);
-                            float t; bool front;
-                            const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front);
-                            const int id = sc.n_mesh + sc.n_tris + si;
-                            n_sph_tests++;
-                            if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                            tri_pos++;
-                            if (tri_pos == tri_end) {
-                                moved = true;
-                                if (sp == 0) fin = true;
-                                else { sp--; next = (int)stk[sp * kWave]; }
+                        if (cur < 0 && cur != kTravDone) {
+                            const int code = ~cur, first = (code & (kSphereLeaf - 1)) >> 3, cnt = (code & 7) + 1;
+                            const int top = (int)stk[(sp - 1) * kWave];
+                            int used;
+                            if (SPH && (code & kSphereLeaf) != 0) {
+                                // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
+                                float4 cr;
+                                int si;
+                                st.sphere(first, cr, si);
+                                float t; bool front;
+                                const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front);
+                                const int id = sc.n_mesh + sc.n_tris + si;
+                                n_sph_tests++;
+                                if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+                                used = 1;
+                            } else {
+                                // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
+                                const bool two = cnt >= 2;
+                                float4 p1, e1, e2, q1, f1, f2;
+                                st.tri(first, p1, e1, e2);
+                                st.tri(two ? first + 1 : first, q1, f1, f2);
+                                float t, det, t2, det2;
+                                bool bad = false;
+                                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad);
+                                bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad);
+                                if (__builtin_expect(bad, 0)) {
+                                    has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
+                                    has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2);
+                                }
+                                const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
+                                n_bvh_tests += two ? 2 : 1;
+                                if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+                                if (two && has2 && (t2 < best_t || (t2 == best_t && id2 < best_id))) { best_t = t2; best_id = id2; }
+                                used = two ? 2 : 1;
                             }
-                        } else if (state == S_MESH && cur < 0) {
-                            // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
-                            const bool two = tri_pos + 1 < tri_end;
-                            float4 p1, e1, e2, q1, f1, f2;
-                            st.tri(tri_pos, p1, e1, e2);
-                            st.tri(two ? tri_pos + 1 : tri_pos, q1, f1, f2);
-                            float t, det, t2, det2;
-                            bool bad = false;
-                            bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad);
-                            bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad);
-                            if (__builtin_expect(bad, 0)) {
-                                has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
-                                has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2);
-                            }
-                            const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
-                            n_bvh_tests += two ? 2 : 1;
-                            if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                            if (two && has2 && (t2 < best_t || (t2 == best_t && id2 < best_id))) { best_t = t2; best_id = id2; }
-                            tri_pos += two ? 2 : 1;
-                            if (tri_pos == tri_end) {
-                                moved = true;
-                                if (sp == 0) fin = true;
-                                else { sp--; next = (int)stk[sp * kWave]; }
-                            }
+                            // primitives left: the leaf code moves on by `used` (first += used, count -= used: ~code falls by
+                            // 8 * used - used); none left: pop
+                            const bool more_left = cnt > used;
+                            new_cur = more_left ? cur - 7 * used : top;
+                            sp -= more_left ? 0 : 1;
                         }
                     }
-                    if (moved) {
+                    const bool fin = new_cur == kTravDone && cur != kTravDone;      // popped the bottom of the stack
+                    cur = new_cur;
+                    if (wave_any(fin)) {
                         if (fin) {
                             // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
                             // the lexicographic minimum of (t, canonical id)
                             if (s_id >= 0 && (s_t < best_t || (s_t == best_t && s_id < best_id))) { best_t = s_t; best_id = s_id; }
                             state = S_READY;
-                        } else if (next >= 0) {
-                            cur = next;
-                        } else {
-                            const int code = ~next;
-                            leaf_sph = SPH && (code & kSphereLeaf) != 0;
-                            tri_pos = (code & (kSphereLeaf - 1)) >> 3; tri_end = tri_pos + (code & 7) + 1;
-                            cur = -1;
                         }
                     }
                 }
@@ -1006,6 +1047,42 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             // ---- direction phase: RandomDirection (rt.comp:85-90) once for both of its callers -- the jitter of a new
             // primary ray (rt.comp:326-333) and the bounce direction of a continuing path (rt.comp:296-305)
             if (wave_ballot(state == S_FRESH) | wave_ballot(state == S_DIR)) {
+#ifdef PT_DUMMY_VALU
+                {   // diagnostic (tools/insitu_cost.sh): PT_DUMMY_VALU extra instructions of kind PT_DUMMY_KIND per iteration; the
+                    // change of the kernel's time prices that instruction form inside the real instruction stream
+                    float dv0 = hp.x, dv1 = hp.y, dv2 = hp.z, dv3 = nrm.x;
+                    const float ds0 = fp.cam[0];
+#pragma unroll
+                    for (int dq = 0; dq < PT_DUMMY_VALU / 4; dq++) {
+#if PT_DUMMY_KIND == 0      // v_fma_f32, VGPR operands
+                        asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 1    // v_min_f32
+                        asm volatile("v_min_f32 %0, %0, %1\n v_min_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_min_f32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 2    // v_cmp_lt_f32 -> vcc
+                        asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3) : : "vcc");
+#elif PT_DUMMY_KIND == 3    // v_cndmask_b32 (vcc)
+                        asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3) : : "vcc");
+#elif PT_DUMMY_KIND == 4    // v_mul_f32 with an SGPR source
+                        asm volatile("v_mul_f32 %0, %4, %0\n v_mul_f32 %1, %4, %1\n v_mul_f32 %2, %4, %2\n v_mul_f32 %3, %4, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3) : "s"(ds0));
+#elif PT_DUMMY_KIND == 5    // v_mul_lo_u32
+                        asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 6    // v_lshrrev_b32
+                        asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 7    // v_rcp_f32
+                        asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 8    // v_mul_f32, VGPR operands
+                        asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %1, %1, %2\n v_mul_f32 %2, %2, %3\n v_mul_f32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 9    // v_max3_f32
+                        asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %0\n v_max3_f32 %3, %3, %0, %1" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#elif PT_DUMMY_KIND == 10   // s_and_b64 (scalar ALU)
+                        asm volatile("s_and_b64 vcc, vcc, exec\n s_and_b64 vcc, vcc, exec\n s_and_b64 vcc, vcc, exec\n s_and_b64 vcc, vcc, exec" : : : "vcc");
+#elif PT_DUMMY_KIND == 11   // v_xor_b32
+                        asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
+#endif
+                    }
+                    if (dv0 + dv1 + dv2 + dv3 == 1.2345e-30f) n_samples++;     // keeps the results alive, practically never true
+                }
+#endif
                 n_samples += __popcll(wave_ballot(state == S_FRESH));
                 if (state == S_FRESH || state == S_DIR) {
                     const bool fresh = state == S_FRESH;
@@ -1017,9 +1094,15 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
                         const v3 jit = (g * 0.00025f) * gr;
                         const float X = -pix_x + jit.x, Y = pix_y + jit.y;
-                        const float *m = fp.iv;
-                        ps.d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
-                        ps.o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
+                        if (st.scene) {     // inverseView and the camera position from the LDS copy: VGPR operands
+                            const float4 m0 = lds_f4(st.scene, 3 * sc.n_tris + 2), m1 = lds_f4(st.scene, 3 * sc.n_tris + 3), m2 = lds_f4(st.scene, 3 * sc.n_tris + 4);
+                            ps.d = normalize(V((m0.x * X + m1.z) + m0.w * Y, (m0.y * X + m1.w) + m1.x * Y, (m0.z * X + m2.x) + m1.y * Y));
+                            ps.o = V(m2.y, m2.z, m2.w);
+                        } else {
+                            const float *m = fp.iv;
+                            ps.d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
+                            ps.o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
+                        }
                         ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
                     } else {
                         const v3 r = g * gr;
@@ -1038,9 +1121,17 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             if (wave_any(state == S_TRACE)) {
                 bool gate = false;
                 if (state == S_TRACE) {
-                    if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
                     s_t = kInfinity; s_id = -1;
-                    scene_closest_tab(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
+                    if (st.scene) {     // root AABB and scene triangles from the LDS copy: VGPR operands
+                        if (sc.n_mesh > 0) {
+                            const float4 bn = lds_f4(st.scene, 3 * sc.n_tris), bx = lds_f4(st.scene, 3 * sc.n_tris + 1);
+                            gate = hit_aabb(V(bn.x, bn.y, bn.z), V(bx.x, bx.y, bx.z), ps.o, ps.d);
+                        }
+                        scene_closest_lds(sc, st.scene, ps.o, ps.d, s_t, s_id, sph_root < 0);
+                    } else {
+                        if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
+                        scene_closest_tab(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
+                    }
                 }
                 n_seg += __popcll(wave_ballot(state == S_TRACE));
                 n_mesh_seg += __popcll(wave_ballot(gate));
@@ -1049,9 +1140,9 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     if (gate || sph_root >= 0) {
                         // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
                         state = S_MESH;
-                        sp = 0; best_t = kInfinity; best_id = -1;
+                        sp = 1; best_t = kInfinity; best_id = -1;
                         cur = gate ? 0 : sph_root;
-                        if (gate && sph_root >= 0) { stk[0] = (unsigned)sph_root; sp = 1; }
+                        if (gate && sph_root >= 0) { stk[kWave] = (unsigned)sph_root; sp = 2; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
                         inv = V(slab_inv(ps.d.x), slab_inv(ps.d.y), slab_inv(ps.d.z));
                         delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
@@ -1196,30 +1287,36 @@ __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, u
 template <bool SPH, bool SHORT>
 __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp, int stack_entries)
 {
-    extern __shared__ unsigned bvh_stack[];      // stack_entries x 4 B x 256 lanes (dynamic: the trees' depth + 1)
+    extern __shared__ float4 bvh_lds_small[];    // wave-uniform operands (kSceneLdsVecs float4) | stacks: stack_entries x 4 B x 256 lanes
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhStore st;
-    st.stack = bvh_stack + wave * (stack_entries * kWave) + lane;
+    const bool staged = stage_scene_lds(bvh_lds_small, sc, fp, threadIdx.x, kLdsBlock);
+    __syncthreads();
+    st.scene = staged ? (lds_cf4v *)bvh_lds_small : nullptr;
+    st.stack = reinterpret_cast<unsigned *>(bvh_lds_small + kSceneLdsVecs) + wave * (stack_entries * kWave) + lane;
     st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
     trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
 }
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
-// LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | stacks (stack_entries x 4 B x 512 lanes).
+// LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | wave-uniform operands (kSceneLdsVecs x 16 B) | stacks
+// (stack_entries x 4 B x 512 lanes).
 constexpr int kBvhLdsBlock = 512;
 template <bool SPH, bool SHORT>
 __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
 {
     extern __shared__ float4 bvh_lds[];
     const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh;
-    unsigned *stack = reinterpret_cast<unsigned *>(sph + n_sph_rec);
+    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
+    unsigned *stack = reinterpret_cast<unsigned *>(scene + kSceneLdsVecs);
     for (int i = threadIdx.x; i < 4 * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
     for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
     for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
+    const bool staged = stage_scene_lds(scene, sc, fp, threadIdx.x, kBvhLdsBlock);
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhLdsStore st;
+    st.scene = staged ? (lds_cf4v *)scene : nullptr;
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
     trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);

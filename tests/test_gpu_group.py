@@ -89,19 +89,40 @@ def test_group_render_reports_a_local_failure_after_the_agreement_round(capi, ca
     a.close()
 
 
-def test_bench_py_self_launches_two_ranks_in_rehearsal_mode():
-    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the ranks before any GPU call.  On a one-GPU box
-    both ranks share cuda:0 and gloo stands in for RCCL (PT_BENCH_REHEARSAL=1): the N > 1 code path end to end, not a measurement"""
+def _bench(args, extra_env, timeout):
     import json
     import os
     import subprocess
     import sys
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PT_BENCH_REHEARSAL="1", GLOO_SOCKET_IFNAME="lo")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
-                       capture_output=True, text=True, timeout=600)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_py_split_path_over_rccl_at_world_one():
+    """the N > 1 code path of bench.py -- process group on RCCL, sum render of this rank's passes, ONE reduce, scale on rank 0 --
+    with the only world size a one-GPU box can give RCCL (PT_BENCH_FORCE_SPLIT=1): not a measurement, the path end to end"""
+    r, d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1"], {"PT_BENCH_FORCE_SPLIT": "1"}, 300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "RCCL" in d["config"]["parallelism"] and d["config"]["spp_total"] == 64
+    assert d["value"] > 0 and d["roofline"]["work_per_launch"]["samples"] == 1920 * 1080 * 64
+    assert 0 < d["config"]["reduce_fraction_of_step"] < 1
+
+
+def test_bench_py_self_launches_two_ranks_in_rehearsal_mode():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns the ranks before any GPU call.  On a one-GPU box
+    both ranks share cuda:0 and gloo stands in for RCCL (PT_BENCH_REHEARSAL=1): the N > 1 code path end to end, not a measurement.
+    Two processes time-slicing ONE GPU is not a supported deployment (one process per GPU is), and on this pool about every
+    second such run stops making progress inside the first gloo reduce whatever kernel variant runs (round 1's brute-force
+    kernel included; tools/exp logs in DESIGN.md 6): the launcher's time limit then ends the job, and this test reports a
+    skip, not a pass.  The launcher itself (ranks, environment, failure propagation, time limit) is tested on the CPU."""
+    r, d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+                  {"PT_BENCH_REHEARSAL": "1", "GLOO_SOCKET_IFNAME": "lo", "PT_LAUNCH_TIMEOUT": "60", "PT_BENCH_TRACEBACK_ON_TERM": "1"}, 150)
+    if r.returncode == 124 and "no result after" in r.stderr:
+        pytest.skip("two ranks sharing one GPU stalled in the gloo reduce (platform; see the docstring)")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert d["n_gpus"] == 2 and d["config"]["spp_total"] == 128 and "REHEARSAL" in d["data"]
     assert d["value"] > 0 and d["roofline"]["work_per_launch"]["samples"] == 1920 * 1080 * 64

@@ -77,7 +77,7 @@ def test_bench_py_launches_its_own_ranks_and_reports_their_failure():
     import pytest
     import torch
     if torch.cuda.is_available():
-        pytest.skip("a GPU is present: covered by the rehearsal test in tests/test_gpu_group.py")
+        pytest.skip("a GPU is present: covered by tests/test_gpu_group.py")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["GLOO_SOCKET_IFNAME"] = "lo"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
