@@ -38,8 +38,9 @@ def scene_blob(sc: S.Scene) -> bytes:
     return hdr + sc.mesh_tris.tobytes() + sc.nodes.tobytes() + sc.materials.tobytes() + sc.spheres.tobytes() + sc.triangles.tobytes()
 
 
-def run_reference(refdir, sc, cam, W, H, passes, bounces, first_pass=1, dump=0, debug_normal=0, every=False, threads=None, dump_bounce=0):
-    """-> (images (n,H,W,4) float32, timing dict).  Row 0 = bottom row (GL origin)."""
+def run_reference(refdir, sc, cam, W, H, passes, bounces, first_pass=1, dump=0, debug_normal=0, every=False, threads=None, dump_bounce=0, frag=False):
+    """-> (images (n,H,W,4) float32, timing dict).  Row 0 = bottom row (GL origin).  frag: run res/shaders/rt.frag (the
+    legacy fullscreen-quad copy of the kernel, drawn into an RGBA32F framebuffer) instead of rt.comp."""
     with tempfile.TemporaryDirectory() as td:
         sp, op = os.path.join(td, "scene.bin"), os.path.join(td, "out.bin")
         with open(sp, "wb") as fh:
@@ -51,6 +52,8 @@ def run_reference(refdir, sc, cam, W, H, passes, bounces, first_pass=1, dump=0, 
                "--inv-view", *[f"{v:.9g}" for v in cam.inv_view_flat()]]
         if every:
             cmd.append("--dump-every-pass")
+        if frag:
+            cmd.append("--frag")
         env = dict(os.environ)
         if threads:
             env["LP_NUM_THREADS"] = str(threads)
@@ -181,6 +184,22 @@ def main():
         img, tm = run_reference(ref, msc, mixed_cam, 640, 360, 4, 16, every=True)
         meta["entries"]["radiance_mixed_b16_640x360"] = {"crc_mean1": crc(img[0, :, :, :3]), "crc_mean4": crc(img[3, :, :, :3]), "llvmpipe_timing": tm}
         print("radiance c1", e)
+
+    # ---- 3a. the legacy rt.frag constant set: rt.frag itself, 12 bounces as shipped and 4 -----
+    if want("frag"):
+        arrs = {}
+        for tag, sc, cam in (("default", dsc, bench_cam), ("mixed", msc, mixed_cam)):
+            for b in (12, 4):
+                img, _ = run_reference(ref, sc, cam, 128, 72, 16, b, every=True, frag=True)
+                for k in (1, 2, 3, 4, 16):
+                    arrs[f"{tag}_b{b}_128x72_mean{k}"] = img[k - 1, :, :, :3].copy()
+                assert np.all(img[:, :, :, 3] == 1.0)
+            img, _ = run_reference(ref, sc, cam, 128, 72, 1, 12, debug_normal=1, frag=True)
+            arrs[f"{tag}_128x72_normal"] = img[0, :, :, :3].copy()
+            img, tm = run_reference(ref, sc, cam, 640, 360, 4, 12, every=True, frag=True)
+            meta["entries"][f"radiance_frag_{tag}_b12_640x360"] = {"crc_mean1": crc(img[0, :, :, :3]), "crc_mean4": crc(img[3, :, :, :3]), "llvmpipe_timing": tm}
+            print("frag", tag)
+        np.savez_compressed(os.path.join(GOLD, "radiance_frag_128x72.npz"), **arrs)
 
     # ---- 3b. per-bounce path state (instrumented shader, llvmpipe_runner --dump 3/4) -----------
     if want("bounce"):

@@ -88,6 +88,19 @@ GLF(void, glDispatchCompute, GLuint, GLuint, GLuint);
 GLF(void, glMemoryBarrier, GLbitfield);
 GLF(void, glFinish, void);
 GLF(void, glGetTexImage, GLenum, GLint, GLenum, GLenum, void *);
+/* fragment-shader mode (--frag): fullscreen quad into an RGBA32F colour attachment */
+GLF(void, glGenFramebuffers, GLsizei, GLuint *);
+GLF(void, glBindFramebuffer, GLenum, GLuint);
+GLF(void, glFramebufferTexture2D, GLenum, GLenum, GLenum, GLuint, GLint);
+GLF(GLenum, glCheckFramebufferStatus, GLenum);
+GLF(void, glGenVertexArrays, GLsizei, GLuint *);
+GLF(void, glBindVertexArray, GLuint);
+GLF(void, glVertexAttribPointer, GLuint, GLint, GLenum, GLboolean, GLsizei, const void *);
+GLF(void, glEnableVertexAttribArray, GLuint);
+GLF(void, glDrawElements, GLenum, GLsizei, GLenum, const void *);
+GLF(void, glViewport, GLint, GLint, GLsizei, GLsizei);
+GLF(void, glActiveTexture, GLenum);
+GLF(void, glDisable, GLenum);
 #define LOAD(name) do { p_##name = (void *)get_proc(#name); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); exit(2); } } while (0)
 
 static void die(const char *m) { fprintf(stderr, "llvmpipe_runner: %s\n", m); exit(2); }
@@ -129,6 +142,9 @@ static void make_context(void)
     LOAD(glGenTextures); LOAD(glBindTexture); LOAD(glTexParameteri); LOAD(glTexImage2D);
     LOAD(glBindImageTexture); LOAD(glDispatchCompute); LOAD(glMemoryBarrier); LOAD(glFinish);
     LOAD(glGetTexImage);
+    LOAD(glGenFramebuffers); LOAD(glBindFramebuffer); LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus);
+    LOAD(glGenVertexArrays); LOAD(glBindVertexArray); LOAD(glVertexAttribPointer); LOAD(glEnableVertexAttribArray);
+    LOAD(glDrawElements); LOAD(glViewport); LOAD(glActiveTexture); LOAD(glDisable);
 }
 
 /* ------------------------------------------------------------ text helpers */
@@ -213,6 +229,36 @@ static char *patch_reference_shader(char *src, int bounces, int instrument)
     return src;
 }
 
+/* The legacy fragment-shader copy of the kernel (res/shaders/rt.frag): same kind of patch -- version
+ * line, the two mix(vec3, vec3, bool) sites inside RayTrace, optionally the bounce literal (12 as shipped). */
+static char *patch_reference_frag(char *src, int bounces)
+{
+    must(subst(&src, 0, "#version 460", "#version 450", 0), "version");
+    char *rt = strstr(src, "vec3 RayTrace(");
+    if (!rt) die("RayTrace not found");
+    size_t rto = rt - src;
+    must(subst(&src, rto, "\t\t\t\t\tisRefracted\n", "\t\t\t\t\tbvec3(isRefracted)\n", 0), "mix bool #1");
+    must(subst(&src, rto, "isSpecularBounce), hitInfo.hitMaterial.baseColor.rgb, isRefracted)",
+                          "bvec3(isSpecularBounce)), hitInfo.hitMaterial.baseColor.rgb, bvec3(isRefracted))", 0), "mix bool #2");
+    if (bounces > 0) {
+        char to[64]; snprintf(to, sizeof to, "debugNormal ? 1 : %d;", bounces);
+        must(subst(&src, 0, "debugNormal ? 1 : 12;", to, 0), "bounce literal");
+    }
+    return src;
+}
+
+static GLuint compile(GLenum kind, const char *src, const char *what)
+{
+    GLuint sh = p_glCreateShader(kind);
+    const GLchar *srcs[1] = { src };
+    p_glShaderSource(sh, 1, srcs, NULL);
+    p_glCompileShader(sh);
+    GLint ok = 0; char log[8192];
+    p_glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+    if (!ok) { p_glGetShaderInfoLog(sh, sizeof log, NULL, log); fprintf(stderr, "%s: compile failed:\n%s\n", what, log); exit(3); }
+    return sh;
+}
+
 /* ------------------------------------------------------------------- main */
 struct scene_hdr { uint32_t magic, n_mesh_tris, n_nodes, n_mats, n_spheres, n_scene_tris; };
 #define SCENE_MAGIC 0x31435350u /* "PSC1" */
@@ -232,7 +278,8 @@ static GLuint make_ssbo(GLuint binding, const void *data, size_t bytes)
 int main(int argc, char **argv)
 {
     const char *refdir = NULL, *shader_file = NULL, *scene_file = NULL, *out_file = NULL, *dump_src = NULL;
-    int W = 64, H = 40, passes = 1, first_pass = 1, bounces = 0, debug_normal = 0, dump = 0, dump_bounce = 0, every = 0, quiet = 0;
+    int W = 64, H = 40, passes = 1, first_pass = 1, bounces = 0, debug_normal = 0, dump = 0, dump_bounce = 0, every = 0, quiet = 0, frag = 0;
+    const char *probe_from[8], *probe_to[8]; int n_probe = 0;
     float cam_pos[3] = { 0, 0, 0 };
     float inv_view[16] = { 0, 0, 1, 0, 0, 1, 0, 0, -1, 0, 0, 0, 0, 0, 0, 1 }; /* default camera, column-major */
     for (int i = 1; i < argc; i++) {
@@ -253,6 +300,11 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--dump-bounce")) dump_bounce = atoi(NEXT()); /* bounce index for --dump 3/4 */
         else if (!strcmp(a, "--dump-every-pass")) every = 1;         /* else only the final accumulation image */
         else if (!strcmp(a, "--quiet")) quiet = 1;
+        else if (!strcmp(a, "--probe-subst")) {                      /* debugging only: one more textual substitution, after the patch */
+            if (n_probe == 8) die("too many --probe-subst");
+            probe_from[n_probe] = NEXT(); probe_to[n_probe++] = NEXT();
+        }
+        else if (!strcmp(a, "--frag")) frag = 1;                     /* run res/shaders/rt.frag (+ rt.vert) instead of rt.comp */
         else if (!strcmp(a, "--cam-pos")) { for (int k = 0; k < 3; k++) cam_pos[k] = strtof(NEXT(), NULL); }
         else if (!strcmp(a, "--inv-view")) { for (int k = 0; k < 16; k++) inv_view[k] = strtof(NEXT(), NULL); }
         else { fprintf(stderr, "unknown arg %s\n", a); return 2; }
@@ -265,23 +317,31 @@ int main(int argc, char **argv)
             p_glGetString(GL_RENDERER), getenv("LP_NUM_THREADS") ? getenv("LP_NUM_THREADS") : "(unset)");
 
     char *src;
-    if (refdir) {
-        char path[4096]; snprintf(path, sizeof path, "%s/res/shaders/rt.comp", refdir);
-        src = patch_reference_shader(read_file(path, NULL), bounces, dump != 0);
-    } else {
-        src = read_file(shader_file, NULL);
-    }
-    if (dump_src) { FILE *f = fopen(dump_src, "w"); fputs(src, f); fclose(f); }
-
-    GLuint sh = p_glCreateShader(GL_COMPUTE_SHADER);
-    const GLchar *srcs[1] = { src };
-    p_glShaderSource(sh, 1, srcs, NULL);
-    p_glCompileShader(sh);
-    GLint ok = 0; char log[8192];
-    p_glGetShaderiv(sh, GL_COMPILE_STATUS, &ok);
-    if (!ok) { p_glGetShaderInfoLog(sh, sizeof log, NULL, log); fprintf(stderr, "compile failed:\n%s\n", log); return 3; }
     GLuint prog = p_glCreateProgram();
-    p_glAttachShader(prog, sh);
+    GLint ok = 0; char log[8192];
+    if (frag) {
+        if (!refdir || dump) die("--frag needs --reference-dir and supports --dump 0 only");
+        char path[4096];
+        snprintf(path, sizeof path, "%s/res/shaders/rt.vert", refdir);
+        char *vsrc = read_file(path, NULL);
+        must(subst(&vsrc, 0, "#version 460", "#version 450", 0), "vert version");
+        snprintf(path, sizeof path, "%s/res/shaders/rt.frag", refdir);
+        src = patch_reference_frag(read_file(path, NULL), bounces);
+        for (int k = 0; k < n_probe; k++) must(subst(&src, 0, probe_from[k], probe_to[k], 0), "--probe-subst");
+        if (dump_src) { FILE *f = fopen(dump_src, "w"); fputs(src, f); fclose(f); }
+        p_glAttachShader(prog, compile(GL_VERTEX_SHADER, vsrc, "rt.vert"));
+        p_glAttachShader(prog, compile(GL_FRAGMENT_SHADER, src, "rt.frag"));
+    } else {
+        if (refdir) {
+            char path[4096]; snprintf(path, sizeof path, "%s/res/shaders/rt.comp", refdir);
+            src = patch_reference_shader(read_file(path, NULL), bounces, dump != 0);
+            for (int k = 0; k < n_probe; k++) must(subst(&src, 0, probe_from[k], probe_to[k], 0), "--probe-subst");
+        } else {
+            src = read_file(shader_file, NULL);
+        }
+        if (dump_src) { FILE *f = fopen(dump_src, "w"); fputs(src, f); fclose(f); }
+        p_glAttachShader(prog, compile(GL_COMPUTE_SHADER, src, "compute shader"));
+    }
     p_glLinkProgram(prog);
     p_glGetProgramiv(prog, GL_LINK_STATUS, &ok);
     if (!ok) { p_glGetProgramInfoLog(prog, sizeof log, NULL, log); fprintf(stderr, "link failed:\n%s\n", log); return 3; }
@@ -302,14 +362,40 @@ int main(int argc, char **argv)
         free(blob);
     }
 
-    /* accumulation image: RGBA32F, zero-initialised (src/Renderer.cpp:117-128 leaves it undefined) */
-    GLuint tex; p_glGenTextures(1, &tex);
-    p_glBindTexture(GL_TEXTURE_2D, tex);
-    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
-    p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+    /* accumulation image: RGBA32F, zero-initialised (src/Renderer.cpp:117-128 leaves it undefined).  Fragment mode: two of
+     * them, sampled / rendered to in turn (the shader reads texture(accumTexture) and writes fragColor, rt.frag:340-342). */
+    GLuint tex[2]; p_glGenTextures(2, tex);
     float *zero = calloc((size_t)W * H * 4, sizeof(float));
-    p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, W, H, 0, GL_RGBA, GL_FLOAT, zero);
-    p_glBindImageTexture(0, tex, 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
+    for (int k = 0; k < (frag ? 2 : 1); k++) {
+        p_glBindTexture(GL_TEXTURE_2D, tex[k]);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_NEAREST);
+        p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_NEAREST);
+        p_glTexImage2D(GL_TEXTURE_2D, 0, GL_RGBA32F, W, H, 0, GL_RGBA, GL_FLOAT, zero);
+    }
+    GLuint fbo = 0;
+    if (!frag) {
+        p_glBindImageTexture(0, tex[0], 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
+    } else {
+        /* the fullscreen quad of src/Renderer.h:11-28 / src/Renderer.cpp:76-95 */
+        static const float quad[20] = { -1, -1, 0,  1, -1, 0,  1, 1, 0,  -1, 1, 0,   0, 0,  1, 0,  1, 1,  0, 1 };
+        static const unsigned idx[6] = { 0, 1, 2, 2, 3, 0 };
+        GLuint vao, vbo, ebo;
+        p_glGenVertexArrays(1, &vao); p_glBindVertexArray(vao);
+        p_glGenBuffers(1, &vbo); p_glBindBuffer(GL_ARRAY_BUFFER, vbo);
+        p_glBufferData(GL_ARRAY_BUFFER, sizeof quad, quad, GL_STATIC_DRAW);
+        p_glGenBuffers(1, &ebo); p_glBindBuffer(GL_ELEMENT_ARRAY_BUFFER, ebo);
+        p_glBufferData(GL_ELEMENT_ARRAY_BUFFER, sizeof idx, idx, GL_STATIC_DRAW);
+        p_glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 0, (void *)0);
+        p_glVertexAttribPointer(1, 2, GL_FLOAT, GL_FALSE, 0, (void *)(12 * sizeof(float)));
+        p_glEnableVertexAttribArray(0); p_glEnableVertexAttribArray(1);
+        p_glGenFramebuffers(1, &fbo);
+        p_glViewport(0, 0, W, H);
+        p_glDisable(GL_DEPTH_TEST); p_glDisable(GL_BLEND); p_glDisable(GL_DITHER);
+        GLint u_tex = p_glGetUniformLocation(prog, "accumTexture");
+        if (u_tex >= 0) p_glUniform1i(u_tex, 0);
+        p_glActiveTexture(GL_TEXTURE0);
+    }
+    GLuint tex_result = tex[0];
 
     GLint u_pass = p_glGetUniformLocation(prog, "currAccumPass");
     GLint u_dbg = p_glGetUniformLocation(prog, "debugNormal");
@@ -331,12 +417,24 @@ int main(int argc, char **argv)
         int pass = first_pass + k;
         double t0 = now_s();
         if (u_pass >= 0) p_glUniform1i(u_pass, pass);
-        p_glDispatchCompute(W / 8, H / 8, 1);                                /* src/Main.cpp:148 */
-        p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
+        if (!frag) {
+            p_glDispatchCompute(W / 8, H / 8, 1);                            /* src/Main.cpp:148 */
+            p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
+        } else {
+            const int src_t = k & 1, dst_t = src_t ^ 1;
+            p_glBindFramebuffer(GL_FRAMEBUFFER, fbo);
+            p_glFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, tex[dst_t], 0);
+            if (k == 0 && p_glCheckFramebufferStatus(GL_FRAMEBUFFER) != GL_FRAMEBUFFER_COMPLETE) die("framebuffer incomplete");
+            p_glBindTexture(GL_TEXTURE_2D, tex[src_t]);
+            p_glDrawElements(GL_TRIANGLES, 6, GL_UNSIGNED_INT, (void *)0);
+            p_glBindFramebuffer(GL_FRAMEBUFFER, 0);
+            tex_result = tex[dst_t];
+        }
         p_glFinish();
         double dt = now_s() - t0;
         if (k == 0) t_first = dt; else t_rest += dt;
         if (every || k == passes - 1) {
+            p_glBindTexture(GL_TEXTURE_2D, tex_result);
             p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, img);
             fwrite(img, sizeof(float), (size_t)W * H * 4, out);
         }

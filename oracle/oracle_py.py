@@ -21,9 +21,15 @@ class OrScene(C.Structure):
                 ("tris", C.c_void_p), ("n_tris", C.c_int32)]
 
 
+class OrParams(C.Structure):
+    _fields_ = [("hit_limit", C.c_float), ("origin_offset", C.c_float), ("jitter_scale", C.c_float), ("sky_color", C.c_float * 3),
+                ("sky_intensity", C.c_float), ("fresnel_n1_one", C.c_int32), ("two_hemisphere_draws", C.c_int32),
+                ("pixel_center", C.c_int32), ("sqrt_output", C.c_int32), ("trace_mesh", C.c_int32), ("sphere_sum_xyz", C.c_int32)]
+
+
 class OrFrame(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("cam_pos", C.c_float * 3), ("inv_view", C.c_float * 16),
-                ("max_bounces", C.c_int32), ("debug_normal", C.c_int32)]
+                ("max_bounces", C.c_int32), ("debug_normal", C.c_int32), ("prm", OrParams)]
 
 
 class OrBounce(C.Structure):
@@ -67,13 +73,16 @@ def lib():
         L.or_primary_ray.argtypes = [C.POINTER(OrFrame), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.or_render_region.argtypes = [C.POINTER(OrScene), C.POINTER(OrFrame)] + [C.c_int32] * 6 + [C.c_void_p]
         L.or_num_threads.restype = C.c_int32
+        L.or_params_preset.argtypes = [C.POINTER(OrParams), C.c_int32]
     return _lib
 
 
 class Oracle:
     """Holds references to the scene arrays (so the pointers stay valid) and a frame description."""
 
-    def __init__(self, scene, camera, width, height, max_bounces, debug_normal=False):
+    def __init__(self, scene, camera, width, height, max_bounces, debug_normal=False, preset=0, params=None):
+        """preset: 0 = res/shaders/rt.comp (the live kernel), 1 = the legacy res/shaders/rt.frag constant set; params: dict
+        of OrParams fields that override the preset"""
         self._keep = [np.ascontiguousarray(a) for a in (scene.mesh_tris, scene.nodes, scene.materials, scene.spheres, scene.triangles)]
         mt, nd, ma, sp, tr = self._keep
         self.scene = OrScene(mt.ctypes.data, len(mt), nd.ctypes.data, len(nd), ma.ctypes.data, len(ma), sp.ctypes.data, len(sp),
@@ -83,6 +92,12 @@ class Oracle:
         self.frame.cam_pos[:] = [float(v) for v in np.asarray(camera.position, np.float32)]
         self.frame.inv_view[:] = [float(v) for v in camera.inv_view_flat()]
         self.frame.max_bounces, self.frame.debug_normal = max_bounces, int(bool(debug_normal))
+        lib().or_params_preset(C.byref(self.frame.prm), preset)
+        for k, v in (params or {}).items():
+            if k == "sky_color":
+                self.frame.prm.sky_color[:] = [float(c) for c in v]
+            else:
+                setattr(self.frame.prm, k, v)
         self.W, self.H = width, height
 
     def render(self, first_pass, n_passes, accum=None):

@@ -31,8 +31,21 @@ static inline float minps(float a, float b) { return a < b ? a : b; }
 static inline float maxps(float a, float b) { return a > b ? a : b; }
 
 #define PT_INFINITY 10000000.0f /* rt.comp:9  */
-#define HIT_LIMIT 0.00001f      /* rt.comp:10 */
 #define TWO_PI 6.28318530718f   /* rt.comp:8  */
+
+void or_params_preset(OrParams *p, int32_t preset)
+{
+    memset(p, 0, sizeof *p);
+    if (preset == 0) {            /* res/shaders/rt.comp */
+        p->hit_limit = 0.00001f; p->origin_offset = 0.0002f; p->jitter_scale = 0.00025f;
+        p->sky_color[0] = p->sky_color[1] = p->sky_color[2] = 1.0f; p->sky_intensity = 0.5f;
+        p->trace_mesh = 1;
+    } else {                      /* res/shaders/rt.frag */
+        p->hit_limit = 0.0f; p->origin_offset = 0.00015f; p->jitter_scale = 0.0005f;
+        p->sky_color[0] = 0.92f; p->sky_color[1] = 0.8f; p->sky_color[2] = 0.85f; p->sky_intensity = 0.8f;
+        p->fresnel_n1_one = 1; p->two_hemisphere_draws = 1; p->pixel_center = 1; p->sqrt_output = 1; p->trace_mesh = 0; p->sphere_sum_xyz = 1;
+    }
+}
 
 /* ---- RNG (rt.comp:68-77) ---- */
 uint32_t or_next_random(uint32_t *state)
@@ -132,28 +145,31 @@ static v3 random_in_hemisphere(v3 n, uint32_t *state)
 }
 
 /* rt.comp:12-13,16,326: pixelIndex = uint(vx/W*2^32 + vy/H*2^32) */
-uint32_t or_pixel_index(int32_t x, int32_t y, int32_t w, int32_t h)
+static uint32_t pixel_index_f(float fx, float fy, int32_t w, int32_t h)
 {
     float W = (float)w, H = (float)h;
-    float vx = (float)x / W, vy = (float)y / H;
+    float vx = fx / W, vy = fy / H;
     float v = (vx / W) * 4294967296.0f + (vy / H) * 4294967296.0f;
     return (uint32_t)v;
 }
+uint32_t or_pixel_index(int32_t x, int32_t y, int32_t w, int32_t h) { return pixel_index_f((float)x, (float)y, w, h); }
 
 /* rt.comp:326-333 */
 uint32_t or_primary_ray(const OrFrame *f, int32_t x, int32_t y, int32_t pass, float origin[3], float dir[3])
 {
     float W = (float)f->width, H = (float)f->height;
-    float vx = (float)x / W, vy = (float)y / H;
+    /* rt.comp:12 integer texel coordinates; rt.frag:14 gl_FragCoord.xy = pixel centres (x + 0.5 is exact in float32) */
+    float fx = f->prm.pixel_center ? (float)x + 0.5f : (float)x, fy = f->prm.pixel_center ? (float)y + 0.5f : (float)y;
+    float vx = fx / W, vy = fy / H;
     float px = ((vx - 0.5f) * W) / H;       /* rt.comp:14,17 */
     float py = vy - 0.5f;
-    uint32_t state = (uint32_t)pass * or_pixel_index(x, y, f->width, f->height);   /* rt.comp:327 */
+    uint32_t state = (uint32_t)pass * pixel_index_f(fx, fy, f->width, f->height);   /* rt.comp:327 */
     /* rt.comp:332 `RandomDirection(s) * 0.00025`: llvmpipe's compiler moves the constant inside the
      * normalize, (v * 0.00025) * (1/sqrt(dot(v,v))) -- pinned by tests/golden primary dirs */
     float gx = or_random_value_nd(&state), gy = or_random_value_nd(&state), gz = or_random_value_nd(&state);
     v3 g = V(gx, gy, gz);
     float gr = 1.0f / sqrtf(dot(g, g));
-    v3 jit = scale(scale(g, 0.00025f), gr);
+    v3 jit = scale(scale(g, f->prm.jitter_scale), gr);
     float X = -px + jit.x, Y = py + jit.y;
     const float *m = f->inv_view;           /* column-major: column k = m[4k..4k+3] */
     /* mat4 * vec4(X, Y, 1, 0) lowers to (c0*X + c2) + c1*Y (App. A.0) */
@@ -180,7 +196,7 @@ static int hit_aabb(const float bmin[4], const float bmax[4], v3 o, v3 d)
 }
 
 /* rt.comp:153-180, hit test part only (normal/material are evaluated for the winner) */
-static inline int hit_triangle(const OrTriangle *tri, v3 o, v3 d, float *t_out, float *det_out)
+static inline int hit_triangle(const OrTriangle *tri, v3 o, v3 d, float hit_limit, float *t_out, float *det_out)
 {
     v3 p1 = V(tri->p1[0], tri->p1[1], tri->p1[2]);
     v3 e1 = sub(V(tri->p2[0], tri->p2[1], tri->p2[2]), p1);
@@ -194,18 +210,20 @@ static inline int hit_triangle(const OrTriangle *tri, v3 o, v3 d, float *t_out, 
     float v = inv * dot(d, r);
     float t = inv * dot(e2, r);
     /* `!(det < 0.0 && det > -0.0)` (rt.comp:173) is always true */
-    int has = t > HIT_LIMIT && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
+    /* rt.frag:151-166 returns early instead: the same predicate, NaN u / v included, with t > 0.0 */
+    int has = t > hit_limit && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
     *t_out = t; *det_out = det;
     return has;
 }
 
 /* rt.comp:126-150; pow(length(v),2) folds to dot(v,v), pow(r,2) to r*r (App. A.0) */
-static inline int hit_sphere(const OrSphere *sp, v3 o, v3 d, float *t_out, int *front_out)
+static inline float length_squared(v3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }     /* rt.frag:89-91 */
+static inline int hit_sphere(const OrSphere *sp, v3 o, v3 d, float hit_limit, int sum_xyz, float *t_out, int *front_out)
 {
     v3 oc = sub(o, V(sp->position[0], sp->position[1], sp->position[2]));
-    float a = dot(d, d);
+    float a = sum_xyz ? length_squared(d) : dot(d, d);
     float hb = dot(oc, d);
-    float c = dot(oc, oc) - sp->radius * sp->radius;
+    float c = (sum_xyz ? length_squared(oc) : dot(oc, oc)) - sp->radius * sp->radius;
     float disc = hb * hb - a * c;
     float sq = sqrtf(disc);
     float t0 = (-hb - sq) / a;
@@ -213,31 +231,32 @@ static inline int hit_sphere(const OrSphere *sp, v3 o, v3 d, float *t_out, int *
     int front = t0 > 0.0f;
     *t_out = front ? t0 : t1;
     *front_out = front;
-    return t0 > HIT_LIMIT || t1 > -HIT_LIMIT;
+    return t0 > hit_limit || t1 > -hit_limit;            /* rt.frag:131: t0 > 0.0 || t1 > -0.0 */
 }
 
 typedef struct { int32_t id; float t; int front; v3 normal; v3 point; uint32_t mat; int gate; } Hit;
 
 /* rt.comp:204-232 */
-static Hit calculate_ray(const OrScene *s, v3 o, v3 d)
+static Hit calculate_ray(const OrScene *s, const OrParams *prm, v3 o, v3 d)
 {
+    const float hit_limit = prm->hit_limit;
     Hit h; memset(&h, 0, sizeof h);
     h.id = -1; h.t = PT_INFINITY;
     const OrTriangle *win_tri = 0; const OrSphere *win_sph = 0; float win_det = 0.0f;
-    h.gate = s->n_nodes > 0 && hit_aabb(s->nodes[0].boundsMin, s->nodes[0].boundsMax, o, d);
+    h.gate = prm->trace_mesh && s->n_nodes > 0 && hit_aabb(s->nodes[0].boundsMin, s->nodes[0].boundsMax, o, d);
     if (h.gate) {
         for (int i = 0; i < s->n_mesh_tris; i++) {
             float t, det;
-            if (hit_triangle(&s->mesh_tris[i], o, d, &t, &det) && t < h.t) { h.t = t; h.id = i; win_tri = &s->mesh_tris[i]; win_det = det; }
+            if (hit_triangle(&s->mesh_tris[i], o, d, hit_limit, &t, &det) && t < h.t) { h.t = t; h.id = i; win_tri = &s->mesh_tris[i]; win_det = det; }
         }
     }
     for (int i = 0; i < s->n_tris; i++) {
         float t, det;
-        if (hit_triangle(&s->tris[i], o, d, &t, &det) && t < h.t) { h.t = t; h.id = s->n_mesh_tris + i; win_tri = &s->tris[i]; win_det = det; }
+        if (hit_triangle(&s->tris[i], o, d, hit_limit, &t, &det) && t < h.t) { h.t = t; h.id = s->n_mesh_tris + i; win_tri = &s->tris[i]; win_det = det; }
     }
     for (int i = 0; i < s->n_spheres; i++) {
         float t; int front;
-        if (hit_sphere(&s->spheres[i], o, d, &t, &front) && t < h.t) { h.t = t; h.id = s->n_mesh_tris + s->n_tris + i; win_tri = 0; win_sph = &s->spheres[i]; h.front = front; }
+        if (hit_sphere(&s->spheres[i], o, d, hit_limit, prm->sphere_sum_xyz, &t, &front) && t < h.t) { h.t = t; h.id = s->n_mesh_tris + s->n_tris + i; win_tri = 0; win_sph = &s->spheres[i]; h.front = front; }
     }
     if (h.id < 0) return h;
     h.point = add(o, scale(d, h.t));
@@ -259,7 +278,8 @@ static Hit calculate_ray(const OrScene *s, v3 o, v3 d)
 
 int32_t or_closest_hit(const OrScene *s, const float o[3], const float d[3], float *t_out, int32_t *front_face, float normal[3])
 {
-    Hit h = calculate_ray(s, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]));
+    OrParams prm; or_params_preset(&prm, 0);
+    Hit h = calculate_ray(s, &prm, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]));
     if (t_out) *t_out = h.t;
     if (front_face) *front_face = h.front;
     if (normal) { normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z; }
@@ -300,8 +320,11 @@ static v3 ray_trace(const OrScene *s, const OrFrame *f, v3 o, v3 d, uint32_t *st
     v3 ray_color = V(1, 1, 1), incoming = V(0, 0, 0), emitted = V(0, 0, 0);
     int max_bounces = f->debug_normal ? 1 : f->max_bounces;     /* rt.comp:23 */
     int bounces = 0;
+    const OrParams *prm = &f->prm;
+    /* skyColor * skyIntensity is a constant expression in both shaders: one float32 product per channel */
+    const v3 sky = V(prm->sky_color[0], prm->sky_color[1], prm->sky_color[2]), sky_emit = scale(sky, prm->sky_intensity);
     for (int i = 0; i < max_bounces; i++) {
-        Hit h = calculate_ray(s, o, d);
+        Hit h = calculate_ray(s, prm, o, d);
         if (counts) { counts[0]++; counts[1] += h.gate; }
         if (trace) {
             OrBounce *b = &trace[*n_trace]; (*n_trace)++;
@@ -317,13 +340,16 @@ static v3 ray_trace(const OrScene *s, const OrFrame *f, v3 o, v3 d, uint32_t *st
             o = h.point;
             float ior = h.front ? (1.0f / m->ior) : m->ior;
             int is_spec = m->specularChance > or_random_value(state);
-            float fres = fresnel_reflect_amount(ior, m->ior, h.normal, d, 1.0f - m->refractionAmount);
+            float fres = fresnel_reflect_amount(prm->fresnel_n1_one ? 1.0f : ior, m->ior, h.normal, d, 1.0f - m->refractionAmount);   /* rt.comp:283 | rt.frag:283 */
             int is_refr = fres < or_random_value(state);
             v3 hemi = random_in_hemisphere(h.normal, state);
+            /* rt.frag:290,295 draws a second hemisphere direction for the refracted branch (both mix() arguments are
+             * evaluated, in source order under llvmpipe: pinned by the rt.frag fixtures) */
+            v3 hemi2 = prm->two_hemisphere_draws ? random_in_hemisphere(h.normal, state) : hemi;
             v3 a = mix3(hemi, reflect3(d, h.normal), is_spec ? m->specularSmoothness : m->smoothness);
-            v3 b = mix3(neg(hemi), refract3(d, h.normal, ior), m->smoothness);
+            v3 b = mix3(neg(hemi2), refract3(d, h.normal, ior), m->smoothness);
             d = normalize(is_refr ? b : a);
-            o = add(o, scale(d, 0.0002f));
+            o = add(o, scale(d, prm->origin_offset));
             v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
             v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
             emitted = add(emitted, scale(V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]), m->emissionStrength));
@@ -331,13 +357,16 @@ static v3 ray_trace(const OrScene *s, const OrFrame *f, v3 o, v3 d, uint32_t *st
             incoming = add(incoming, mul(emitted, ray_color));
         } else {
             bounces++;
-            emitted = add(emitted, V(0.5f, 0.5f, 0.5f));        /* skyColor * skyIntensity, rt.comp:315 */
-            incoming = add(incoming, mul(emitted, ray_color)); /* rayColor *= vec3(1) is exact */
+            emitted = add(emitted, sky_emit);                   /* skyColor * skyIntensity, rt.comp:315 */
+            ray_color = mul(ray_color, sky);                    /* rt.comp:316: * vec3(1), exact */
+            incoming = add(incoming, mul(emitted, ray_color));
             break;
         }
     }
     float nb = (float)bounces;
-    return V(incoming.x / nb, incoming.y / nb, incoming.z / nb);
+    v3 c = V(incoming.x / nb, incoming.y / nb, incoming.z / nb);
+    if (prm->sqrt_output) c = V(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));      /* rt.frag:320 */
+    return c;
 }
 
 void or_ray_trace(const OrScene *s, const OrFrame *f, float o[3], float d[3], uint32_t *state, float rgb[3], OrBounce *trace, int32_t *n_trace)
@@ -410,7 +439,7 @@ void or_primary_hits(const OrScene *s, const OrFrame *f, int32_t pass, int32_t *
             uint32_t st = or_primary_ray(f, x, y, pass, o, d);
             size_t i = (size_t)y * f->width + x;
             if (ids || t) {
-                Hit h = calculate_ray(s, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]));
+                Hit h = calculate_ray(s, &f->prm, V(o[0], o[1], o[2]), V(d[0], d[1], d[2]));
                 if (ids) ids[i] = h.id;
                 if (t) t[i] = h.t;
             }

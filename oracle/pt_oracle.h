@@ -35,17 +35,38 @@ typedef struct {
     const OrTriangle *tris;      int32_t n_tris;        /* SSBO 5  rt.comp:64-66 */
 } OrScene;
 
+/* The constants in which the reference's legacy copy of the kernel, res/shaders/rt.frag, differs from rt.comp.
+ * Parity status of the rt.frag values: PINNED by fixtures of rt.frag itself run under llvmpipe (llvmpipe_runner --frag,
+ * tests/golden/radiance_frag_128x72.npz).  PI / TWO_PI are not here: 6.28318530 (rt.frag:4) and 6.28318530718 (rt.comp:8)
+ * are the same float32. */
+typedef struct {
+    float hit_limit;              /* rt.comp:10,146,173: 1e-5 | rt.frag:131,166: 0 (t > 0.0; t0 > 0.0 || t1 > -0.0) */
+    float origin_offset;          /* rt.comp:305: 0.0002     | rt.frag:303: 0.00015 */
+    float jitter_scale;           /* rt.comp:332: 0.00025    | rt.frag:332: 0.0005 */
+    float sky_color[3];           /* rt.comp:25: (1,1,1)     | rt.frag:253: (0.92, 0.8, 0.85); also multiplies rayColor at the miss */
+    float sky_intensity;          /* rt.comp:26: 0.5         | rt.frag:254: 0.8 */
+    int32_t fresnel_n1_one;       /* rt.comp:283: n1 = ior (1/ior on a front face) | rt.frag:283: n1 = 1.0 */
+    int32_t two_hemisphere_draws; /* rt.comp:287: one RandomInHemisphere, used twice | rt.frag:290,295: two draws (14 per bounce) */
+    int32_t pixel_center;         /* rt.comp:12: integer texel coordinates | rt.frag:14: gl_FragCoord (x + 0.5, y + 0.5) */
+    int32_t sqrt_output;          /* rt.comp:322: incoming / bounces | rt.frag:320: sqrt(incoming / bounces) */
+    int32_t trace_mesh;           /* rt.comp:213-218: mesh behind the root-AABB gate | rt.frag:207-216: commented out */
+    int32_t sphere_sum_xyz;       /* sphere a, c: rt.comp:130-132 pow(length(v),2) = dot(v,v), summed (z*z + y*y) + x*x by llvmpipe |
+                                   * rt.frag:89-91,122-124 LengthSquared(v), written out as (x*x + y*y) + z*z */
+} OrParams;
+
 typedef struct {
     int32_t width, height;
     float cam_pos[3];        /* uniform cam.position     rt.comp:30 */
     float inv_view[16];      /* uniform cam.inverseView  rt.comp:31, column-major */
     int32_t max_bounces;     /* literal 3 at rt.comp:23; runtime here (BASELINE configs use 4/8/16) */
     int32_t debug_normal;    /* uniform debugNormal      rt.comp:21 */
+    OrParams prm;            /* fill with or_params_preset(): 0 = rt.comp (the live kernel), 1 = rt.frag (legacy) */
 } OrFrame;
 
 /* per-bounce record for divergence debugging (tests/golden per-pixel traces) */
 typedef struct { float origin[3], dir[3]; int32_t prim_id; float t; uint32_t rng_state; } OrBounce;
 
+void or_params_preset(OrParams *p, int32_t preset);
 /* rt.comp:68-73 */ uint32_t or_next_random(uint32_t *state);
 /* rt.comp:75-77 */ float or_random_value(uint32_t *state);
 /* llvmpipe log()/cos() as lowered for rt.comp:80-82 (gallivm polynomial forms, fused mads) */

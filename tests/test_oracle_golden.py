@@ -127,3 +127,40 @@ def test_per_bounce_state(tag, cameras, scenes):
                 assert np.uint32(nxt[4]) == d3[y, x, 3].view(np.uint32)
                 checked += 1
         assert checked > 0
+
+
+# ---- the legacy constant set: res/shaders/rt.frag run under llvmpipe (oracle/llvmpipe_runner --frag) -------------------
+@pytest.mark.parametrize("tag,bounces", [("default", 12), ("default", 4), ("mixed", 12), ("mixed", 4)])
+def test_frag_preset_running_mean_bit_exact(tag, bounces, cameras, scenes):
+    sc, cam = scenes[SCENE_CAM[tag][0]], cameras[SCENE_CAM[tag][1]]
+    g = np.load(os.path.join(GOLD, "radiance_frag_128x72.npz"))
+    o = O.Oracle(sc, cam, 128, 72, bounces, preset=1)
+    acc = np.zeros((72, 128, 4), np.float32)
+    for k in range(1, 17):
+        o.render(k, 1, acc)
+        if k in (1, 2, 3, 4, 16):
+            assert n_diff_pixels(acc[:, :, :3], g[f"{tag}_b{bounces}_128x72_mean{k}"]) == 0, f"running mean after pass {k}"
+
+
+@pytest.mark.parametrize("tag", ["default", "mixed"])
+def test_frag_preset_debug_normal_and_640x360(tag, meta, cameras, scenes):
+    sc, cam = scenes[SCENE_CAM[tag][0]], cameras[SCENE_CAM[tag][1]]
+    g = np.load(os.path.join(GOLD, "radiance_frag_128x72.npz"))
+    acc = O.Oracle(sc, cam, 128, 72, 12, debug_normal=True, preset=1).render(1, 1)
+    assert n_diff_pixels(acc[:, :, :3], g[f"{tag}_128x72_normal"]) == 0
+    acc = O.Oracle(sc, cam, 640, 360, 12, preset=1).render(1, 4)
+    assert crc(acc[:, :, :3]) == meta[f"radiance_frag_{tag}_b12_640x360"]["crc_mean4"]
+
+
+def test_frag_preset_fields_each_matter(meta, cameras, scenes):
+    """every field in which preset 1 differs from preset 0 changes the mixed-scene image (so the fixtures pin each one);
+    the hit limit only shows at 640x360 (4 pixels of the 4-pass mean), pinned there by the CRC"""
+    sc, cam = scenes["mixed"], cameras["mixed"]
+    acc = O.Oracle(sc, cam, 640, 360, 12, preset=1, params={"hit_limit": 0.00001}).render(1, 4)
+    assert crc(acc[:, :, :3]) != meta["radiance_frag_mixed_b12_640x360"]["crc_mean4"]
+    g = np.load(os.path.join(GOLD, "radiance_frag_128x72.npz"))["mixed_b12_128x72_mean2"]
+    rt_comp = {"origin_offset": 0.0002, "jitter_scale": 0.00025, "sky_color": (1.0, 1.0, 1.0), "sky_intensity": 0.5,
+               "fresnel_n1_one": 0, "two_hemisphere_draws": 0, "pixel_center": 0, "sqrt_output": 0, "sphere_sum_xyz": 0}
+    for k, v in rt_comp.items():
+        acc = O.Oracle(sc, cam, 128, 72, 12, preset=1, params={k: v}).render(1, 2)
+        assert n_diff_pixels(acc[:, :, :3], g) > 0, k
