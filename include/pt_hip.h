@@ -92,6 +92,32 @@ int pt_set_debug_normal(pt_ctx *ctx, int enabled);
 /* the literal 3 at rt.comp:23 (12 in the legacy rt.frag:337); BASELINE configs use 4/8/16 */
 int pt_set_max_bounces(pt_ctx *ctx, int max_bounces);
 
+/* The literals in which the reference's legacy copy of the kernel, res/shaders/rt.frag, differs from res/shaders/rt.comp
+ * (SURVEY App. B).  They are arguments of the same kernels (wave-uniform, one code path), the rt.comp values being the
+ * defaults of a new context.  Both presets are pinned bit-exact against the reference's own shader run under llvmpipe
+ * (tests/golden/radiance_128x72.npz: rt.comp, radiance_frag_128x72.npz: rt.frag); other combinations are checked against
+ * the CPU oracle only.  PI / TWO_PI are not here: 6.28318530 (rt.frag:4) and 6.28318530718 (rt.comp:8) are the same float. */
+typedef struct PtShadingParams {
+    float hit_limit;              /* rt.comp:10,146,173: 1e-5 | rt.frag:131,166: 0 (t > 0.0; t0 > 0.0 || t1 > -0.0);  0 .. 1e-3 */
+    float origin_offset;          /* rt.comp:305: 0.0002      | rt.frag:303: 0.00015 */
+    float jitter_scale;           /* rt.comp:332: 0.00025     | rt.frag:332: 0.0005 */
+    float sky_color[3];           /* rt.comp:25: (1, 1, 1)    | rt.frag:253: (0.92, 0.8, 0.85); also multiplies rayColor at the miss */
+    float sky_intensity;          /* rt.comp:26: 0.5          | rt.frag:254: 0.8 */
+    int32_t fresnel_n1_one;       /* rt.comp:283: FresnelReflectAmount(n1 = ior, ...) | rt.frag:283: n1 = 1.0 */
+    int32_t two_hemisphere_draws; /* rt.comp:287: one RandomInHemisphere, used twice | rt.frag:290,295: two draws (14 per bounce) */
+    int32_t pixel_center;         /* rt.comp:12: integer texel coordinates | rt.frag:14: gl_FragCoord.xy = (x + 0.5, y + 0.5) */
+    int32_t sqrt_output;          /* rt.comp:322: incoming / bounces | rt.frag:320: sqrt(incoming / bounces) */
+    int32_t trace_mesh;           /* rt.comp:213-218: mesh behind the root-AABB gate | rt.frag:207-216: both mesh loops commented out */
+    int32_t sphere_sum_xyz;       /* sphere a, c: rt.comp:130-132 pow(length(v),2), which the reference's compiler sums (z*z + y*y) + x*x |
+                                   * rt.frag:89-91,122-124 LengthSquared(v), written out as (x*x + y*y) + z*z */
+} PtShadingParams;
+/* preset 0 = rt.comp (what pt_create sets), 1 = rt.frag (bounces are separate: pt_set_max_bounces(ctx, 12), rt.frag:337) */
+int pt_shading_preset(PtShadingParams *out, int preset);
+/* Takes effect at the next render call; resets nothing else (the accumulation image is the caller's to clear).  Non-finite
+ * values, a negative limit / offset / scale, hit_limit > 1e-3 and flags other than 0 / 1 return PT_E_INVALID. */
+int pt_set_shading_params(pt_ctx *ctx, const PtShadingParams *params);
+int pt_get_shading_params(pt_ctx *ctx, PtShadingParams *out);
+
 /* --- tracing */
 /* One accumulation pass == SetUniform1i("currAccumPass", pass) + glDispatchCompute + glMemoryBarrier
  * (src/Main.cpp:144-150): accum = mix(accum, radiance(pass), 1/pass) (rt.comp:337-339). */

@@ -22,10 +22,31 @@ SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_resize", "pt_set_accum_buffer", "pt_set_stream", "pt_upload_mesh",
     "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render", "pt_render_static",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
-    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_set_option", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
+    "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_set_option",
+    "pt_shading_preset", "pt_set_shading_params", "pt_get_shading_params", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
     "pt_kernel_name", "pt_last_kernel_name",
     "pt_version",
 ]
+
+
+class PtShadingParams(C.Structure):
+    """include/pt_hip.h PtShadingParams: the literals in which res/shaders/rt.frag differs from rt.comp"""
+    _fields_ = [("hit_limit", C.c_float), ("origin_offset", C.c_float), ("jitter_scale", C.c_float), ("sky_color", C.c_float * 3),
+                ("sky_intensity", C.c_float), ("fresnel_n1_one", C.c_int32), ("two_hemisphere_draws", C.c_int32),
+                ("pixel_center", C.c_int32), ("sqrt_output", C.c_int32), ("trace_mesh", C.c_int32), ("sphere_sum_xyz", C.c_int32)]
+
+    def as_dict(self):
+        return {n: (tuple(getattr(self, n)) if n == "sky_color" else getattr(self, n)) for n, _ in self._fields_}
+
+
+RT_COMP, RT_FRAG = 0, 1      # pt_shading_preset
+
+
+def shading_preset(preset: int) -> PtShadingParams:
+    p = PtShadingParams()
+    if load().pt_shading_preset(C.byref(p), int(preset)) != 0:
+        raise ValueError(f"no shading preset {preset}")
+    return p
 
 
 class PtCounters(C.Structure):
@@ -108,6 +129,9 @@ def load():
     L.pt_last_render_ms.argtypes = [vp, f32p, C.POINTER(C.c_int)]
     L.pt_set_tuning.argtypes = [vp, i32, C.c_size_t, i32, i32]
     L.pt_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.pt_shading_preset.argtypes = [C.POINTER(PtShadingParams), i32]
+    L.pt_set_shading_params.argtypes = [vp, C.POINTER(PtShadingParams)]
+    L.pt_get_shading_params.argtypes = [vp, C.POINTER(PtShadingParams)]
     L.pt_bvh_selftest.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
     L.pt_group_unique_id.argtypes = [C.c_char_p]
     L.pt_group_init.argtypes = [vp, C.c_char_p, i32, i32]
@@ -255,6 +279,23 @@ class Renderer:
 
     def set_option(self, name, value):
         self._ck(self.L.pt_set_option(self.h, name.encode(), int(value)))
+
+    def set_shading_params(self, preset=None, **fields):
+        """pt_set_shading_params: start from `preset` (RT_COMP / RT_FRAG) or from the current values, override `fields`."""
+        p = shading_preset(preset) if preset is not None else self.shading_params()
+        for k, v in fields.items():
+            if k == "sky_color":
+                p.sky_color = (C.c_float * 3)(*v)
+            elif k in dict(PtShadingParams._fields_):
+                setattr(p, k, v)
+            else:
+                raise KeyError(k)
+        self._ck(self.L.pt_set_shading_params(self.h, C.byref(p)))
+
+    def shading_params(self) -> PtShadingParams:
+        p = PtShadingParams()
+        self._ck(self.L.pt_get_shading_params(self.h, C.byref(p)))
+        return p
 
 
 def bvh_selftest(tris):

@@ -129,6 +129,8 @@ struct pt_ctx {
     float cam[3] = {0, 0, 0}, iv[9] = {0};
     int max_bounces = 3;              // rt.comp:23
     int debug_normal = 0;
+    PtShadingParams shading;          // pt_set_shading_params; pt_create fills in preset 0 (rt.comp)
+    std::vector<float> h_ior;         // material.ior of the uploaded materials (the Fresnel table depends on shading.fresnel_n1_one)
     // scheduling options (pt_set_option; 0 = the built-in choice for the launch at hand)
     int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0, opt_wgs_per_cu = 0;
 };
@@ -181,9 +183,56 @@ int check_ready(pt_ctx *c)
     return PT_OK;
 }
 
+// PtShadingParams -> what the kernels take (pt_kernels.hpp Shading)
+Shading shading_of(const PtShadingParams &p)
+{
+    Shading h;
+    h.hit_limit = p.hit_limit; h.origin_offset = p.origin_offset; h.jitter_scale = p.jitter_scale;
+    for (int k = 0; k < 3; k++) {
+        volatile float e = p.sky_color[k] * p.sky_intensity;      // one float32 rounding, as the shader's compiler folds the constants
+        h.sky[k] = p.sky_color[k]; h.sky_emit[k] = e;
+    }
+    // a sphere counts as hit down to t1 = -hit_limit (rt.comp:146): boxes that end before that, less a margin, are skipped
+    h.box_slack = std::min(kBoxSlack, -10.0f * p.hit_limit);
+    h.pix_off = p.pixel_center ? 0.5f : 0.0f;
+    h.flags = (p.fresnel_n1_one ? kShN1One : 0) | (p.two_hemisphere_draws ? kShTwoDraws : 0) | (p.sqrt_output ? kShSqrtOut : 0)
+              | (p.sphere_sum_xyz ? kShSumXyz : 0) | (p.trace_mesh ? kShTraceMesh : 0);
+    return h;
+}
+
+// the traversal kernels' GEN instantiation (pt_kernels.hpp trace_items_body_bvh) is needed
+bool generic_shading(const Shading &h) { return h.flags != kShDefault || h.hit_limit != kHitLimit || h.box_slack != kBoxSlack; }
+
+// What FresnelReflectAmount (rt.comp:235-254) divides, per material: (1 / ior, r0 of a front-face hit, n1 / n2 of a front-face
+// hit, r0 of a back-face hit); a back-face hit takes n1 / n2 from the first entry when it needs one.  Host floats are IEEE
+// binary32 and this file is built without contraction, so these are the values the kernel's own divisions would produce.
+//   rt.comp:283  n1 = ior = front ? 1 / material.ior : material.ior, n2 = material.ior (a back-face hit has n1 = n2: r0 = 0)
+//   rt.frag:283  n1 = 1.0 on both faces: r0 = ((1 - n2) / (1 + n2))^2, n1 / n2 = 1 / n2
+int upload_fresnel_table(pt_ctx *c)
+{
+    const int n = (int)c->h_ior.size();
+    std::vector<float> fres((size_t)std::max(1, n) * 4, 0.0f);
+    for (int i = 0; i < n; i++) {
+        volatile float n2 = c->h_ior[i];
+        volatile float inv = 1.0f / n2;                            // rt.comp:281
+        if (c->shading.fresnel_n1_one) {
+            volatile float q = (1.0f - n2) / (1.0f + n2);
+            fres[4 * i + 0] = inv; fres[4 * i + 1] = q * q; fres[4 * i + 2] = inv; fres[4 * i + 3] = q * q;
+        } else {
+            volatile float q = (inv - n2) / (inv + n2);
+            volatile float qb = (n2 - n2) / (n2 + n2);
+            fres[4 * i + 0] = inv; fres[4 * i + 1] = q * q; fres[4 * i + 2] = inv / n2; fres[4 * i + 3] = qb * qb;
+        }
+    }
+    HIPCHK(c, c->mat_fres.upload(fres.data(), fres.size() * sizeof(float), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                    // the staging vector dies here
+    return PT_OK;
+}
+
 SceneView scene_view(const pt_ctx *c)
 {
     SceneView s;
+    s.sh = shading_of(c->shading);
     s.mesh_soa = (const float *)c->mesh_soa.p;
     s.mesh_p1 = (const float4 *)c->mesh_p1.p; s.mesh_e1 = (const float4 *)c->mesh_e1.p;
     s.mesh_e2 = (const float4 *)c->mesh_e2.p; s.mesh_nrm = (const float4 *)c->mesh_nrm.p;
@@ -216,6 +265,16 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     f.counters = (unsigned long long *)c->counters.p;
     return f;
 }
+
+// The traversal kernels by [scene has a sphere tree][few passes: fused accumulation][kSh* flags other than rt.comp's]
+// (template arguments SPH, SHORT, GEN of pt_kernels.hpp), with the names rocprofv3 reports them under.
+struct BvhKernel { const void *fn; const char *name; };
+#define PT_BVH_ROW(K, S, F) { { (const void *)&K<S, F, false>, #K "<" #S ", " #F ", false>" }, { (const void *)&K<S, F, true>, #K "<" #S ", " #F ", true>" } }
+const BvhKernel kBvhLdsKernels[2][2][2] = { { PT_BVH_ROW(pt_trace_items_bvh_lds, false, false), PT_BVH_ROW(pt_trace_items_bvh_lds, false, true) },
+                                            { PT_BVH_ROW(pt_trace_items_bvh_lds, true, false), PT_BVH_ROW(pt_trace_items_bvh_lds, true, true) } };
+const BvhKernel kBvhKernels[2][2][2] = { { PT_BVH_ROW(pt_trace_items_bvh, false, false), PT_BVH_ROW(pt_trace_items_bvh, false, true) },
+                                         { PT_BVH_ROW(pt_trace_items_bvh, true, false), PT_BVH_ROW(pt_trace_items_bvh, true, true) } };
+#undef PT_BVH_ROW
 
 // Per-lane stack entries beyond the trees' depth: the permanent bottom entry, the other tree's root (counted in bvh_depth), and
 // the free slot above the stack that every node visit writes unconditionally.
@@ -397,26 +456,24 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
         } else if (variant == 6) {
             const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * (c->opt_wgs_per_cu ? c->opt_wgs_per_cu : 2));
             const size_t lds = bvh_lds_bytes(c);
-            const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_bvh_lds<true, true> : (const void *)&pt_trace_items_bvh_lds<true, false>)
-                                                : (fused ? (const void *)&pt_trace_items_bvh_lds<false, true> : (const void *)&pt_trace_items_bvh_lds<false, false>);
+            const BvhKernel &bk = kBvhLdsKernels[c->sph_root >= 0][fused][generic_shading(sv.sh)];
+            const void *kern = bk.fn;
             HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + kBvhStackExtra;
             void *args[] = {&sv, &fp, &n_nodes, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
-            c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh_lds<true, true>" : "pt_trace_items_bvh_lds<true, false>")
-                                              : (fused ? "pt_trace_items_bvh_lds<false, true>" : "pt_trace_items_bvh_lds<false, false>");
+            c->last_kernel = bk.name;
         } else if (variant == 5) {
             // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
             const size_t lds = (size_t)kSceneLdsVecs * 16 + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * kLdsBlock;
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / (lds + 512)));
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * per_cu);
-            const void *kern = c->sph_root >= 0 ? (fused ? (const void *)&pt_trace_items_bvh<true, true> : (const void *)&pt_trace_items_bvh<true, false>)
-                                                : (fused ? (const void *)&pt_trace_items_bvh<false, true> : (const void *)&pt_trace_items_bvh<false, false>);
+            const BvhKernel &bk = kBvhKernels[c->sph_root >= 0][fused][generic_shading(sv.sh)];
+            const void *kern = bk.fn;
             int entries = c->bvh_depth + kBvhStackExtra;
             void *args[] = {&sv, &fp, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kLdsBlock), args, lds, c->stream));
-            c->last_kernel = c->sph_root >= 0 ? (fused ? "pt_trace_items_bvh<true, true>" : "pt_trace_items_bvh<true, false>")
-                                              : (fused ? "pt_trace_items_bvh<false, true>" : "pt_trace_items_bvh<false, false>");
+            c->last_kernel = bk.name;
         } else {
             const unsigned grid = (unsigned)std::min<long long>((items + 3) / 4, (long long)c->n_cus * 6);
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 6>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
@@ -455,6 +512,7 @@ int pt_create(pt_ctx **out, int device)
     if (device < 0 || device >= n) return fail(nullptr, PT_E_INVALID, "device %d out of range [0,%d)", device, n);
     pt_ctx *c = new pt_ctx();
     c->device = device;
+    pt_shading_preset(&c->shading, 0);
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
         fail(nullptr, PT_E_HIP, "context setup failed: %s", hipGetErrorString(e));
         delete c;
@@ -634,19 +692,9 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     HIPCHK(c, c->sph.upload(sp.data(), sp.size() * sizeof(float4), c->stream));
     HIPCHK(c, c->sph_mat.upload(sm.data(), sm.size() * sizeof(uint32_t), c->stream));
     HIPCHK(c, c->mats.upload(mats, (size_t)n_mats * sizeof(PtMaterial), c->stream));
-    // what FresnelReflectAmount (rt.comp:235-254) divides, per material: host floats are IEEE binary32 and this file
-    // is built without contraction, so these are the values the kernel's own divisions would produce
-    std::vector<float> fres((size_t)std::max(1, n_mats) * 4, 0.0f);     // lives until the stream is synchronised below
-    {
-        for (int i = 0; i < n_mats; i++) {
-            volatile float n2 = mats[i].ior;
-            volatile float n1 = 1.0f / n2;                         // front face: ior = 1 / material.ior (rt.comp:281)
-            volatile float q = (n1 - n2) / (n1 + n2);
-            volatile float qb = (n2 - n2) / (n2 + n2);             // back face: n1 = n2 = material.ior
-            fres[4 * i + 0] = n1; fres[4 * i + 1] = q * q; fres[4 * i + 2] = n1 / n2; fres[4 * i + 3] = qb * qb;
-        }
-        HIPCHK(c, c->mat_fres.upload(fres.data(), fres.size() * sizeof(float), c->stream));
-    }
+    c->h_ior.resize((size_t)n_mats);
+    for (int i = 0; i < n_mats; i++) c->h_ior[i] = mats[i].ior;
+    { const int rc = upload_fresnel_table(c); if (rc != PT_OK) return rc; }
     // sphere tree for the traversal variants (records in leaf order: (centre, radius), (bits(index), 0, 0, 0))
     c->sph_bvh_ok = false; c->nodes_dirty = true;
     std::vector<float4> srec;
@@ -698,6 +746,50 @@ int pt_set_max_bounces(pt_ctx *c, int n)
     if (!c) return PT_E_INVALID;
     if (n < 1 || n > 4096) return fail(c, PT_E_INVALID, "max_bounces %d outside [1,4096]", n);
     c->max_bounces = n;
+    return PT_OK;
+}
+
+int pt_shading_preset(PtShadingParams *p, int preset)
+{
+    if (!p || preset < 0 || preset > 1) return PT_E_INVALID;
+    std::memset(p, 0, sizeof *p);
+    if (preset == 0) {            // res/shaders/rt.comp:10,25-26,305,332
+        p->hit_limit = kHitLimit; p->origin_offset = 0.0002f; p->jitter_scale = 0.00025f;
+        p->sky_color[0] = p->sky_color[1] = p->sky_color[2] = 1.0f; p->sky_intensity = 0.5f;
+        p->trace_mesh = 1;
+    } else {                      // res/shaders/rt.frag:131,166,253-254,283,290-295,303,320,332
+        p->hit_limit = 0.0f; p->origin_offset = 0.00015f; p->jitter_scale = 0.0005f;
+        p->sky_color[0] = 0.92f; p->sky_color[1] = 0.8f; p->sky_color[2] = 0.85f; p->sky_intensity = 0.8f;
+        p->fresnel_n1_one = 1; p->two_hemisphere_draws = 1; p->pixel_center = 1; p->sqrt_output = 1; p->trace_mesh = 0; p->sphere_sum_xyz = 1;
+    }
+    return PT_OK;
+}
+
+int pt_set_shading_params(pt_ctx *c, const PtShadingParams *p)
+{
+    if (!c) return PT_E_INVALID;
+    if (!p) return fail(c, PT_E_INVALID, "params is NULL");
+    const float v[7] = {p->hit_limit, p->origin_offset, p->jitter_scale, p->sky_color[0], p->sky_color[1], p->sky_color[2], p->sky_intensity};
+    for (float x : v) if (!std::isfinite(x)) return fail(c, PT_E_INVALID, "shading parameters must be finite");
+    if (p->hit_limit < 0.0f || p->hit_limit > 1e-3f) return fail(c, PT_E_INVALID, "hit_limit %g outside [0, 1e-3]", (double)p->hit_limit);
+    if (p->origin_offset < 0.0f || p->jitter_scale < 0.0f) return fail(c, PT_E_INVALID, "origin_offset and jitter_scale must not be negative");
+    const int32_t flags[6] = {p->fresnel_n1_one, p->two_hemisphere_draws, p->pixel_center, p->sqrt_output, p->trace_mesh, p->sphere_sum_xyz};
+    for (int32_t f : flags) if (f != 0 && f != 1) return fail(c, PT_E_INVALID, "shading flags are 0 or 1");
+    const bool table = p->fresnel_n1_one != c->shading.fresnel_n1_one;
+    c->shading = *p;
+    c->order_dirty = true;        // the tile schedule looks at pixel centres and at whether the mesh is traced
+    if (table && c->have_scene) {
+        Bind b(c); HIPCHK(c, b.e);
+        HIPCHK(c, hipStreamSynchronize(c->stream));                 // no launch may still be reading the old table
+        return upload_fresnel_table(c);
+    }
+    return PT_OK;
+}
+
+int pt_get_shading_params(pt_ctx *c, PtShadingParams *out)
+{
+    if (!c || !out) return PT_E_INVALID;
+    *out = c->shading;
     return PT_OK;
 }
 
@@ -873,7 +965,17 @@ Rccl &rccl()
     return r;
 }
 constexpr int kNcclFloat32 = 7, kNcclInt32 = 2, kNcclSum = 0, kNcclMax = 2;     // rccl.h ncclDataType_t / ncclRedOp_t
-constexpr int kGroupAgree = 13;            // six shared arguments as (x, -x) pairs + one status word
+constexpr int kGroupAgree = 15;            // seven shared arguments as (x, -x) pairs + one status word
+// 31-bit FNV-1a of the shading parameters (pt_group_render: every rank must shade alike)
+int shading_hash(const PtShadingParams &p)
+{
+    const float fl[7] = {p.hit_limit, p.origin_offset, p.jitter_scale, p.sky_color[0], p.sky_color[1], p.sky_color[2], p.sky_intensity};
+    const int32_t in[6] = {p.fresnel_n1_one, p.two_hemisphere_draws, p.pixel_center, p.sqrt_output, p.trace_mesh, p.sphere_sum_xyz};
+    uint32_t h = 2166136261u;
+    auto eat = [&](const void *q, size_t n) { for (size_t i = 0; i < n; i++) h = (h ^ ((const unsigned char *)q)[i]) * 16777619u; };
+    eat(fl, sizeof fl); eat(in, sizeof in);
+    return (int)(h & 0x7fffffffu);
+}
 }  // namespace
 }  // extern "C++"
 
@@ -913,15 +1015,16 @@ int pt_group_render(pt_ctx *c, int first_pass, int total_spp)
     Bind b(c); HIPCHK(c, b.e);
     Rccl &r = rccl();
     // A collective must not be left by one rank alone: whatever is wrong locally (bad arguments, scene not uploaded) is
-    // first shared with the other ranks -- ONE all-reduce (max) of thirteen ints: the arguments every rank must agree on, each
+    // first shared with the other ranks -- ONE all-reduce (max) of fifteen ints: the arguments every rank must agree on, each
     // together with its negative (max of -x = -min of x), and this rank's local status -- and only then does anybody return.
     int local = PT_OK;
     if (first_pass < 1 || total_spp < 1) local = fail(c, PT_E_INVALID, "bad pass range %d+%d", first_pass, total_spp);
     if (local == PT_OK) local = check_ready(c);
-    const int mine[6] = {first_pass, total_spp, c->width, c->height, c->max_bounces, c->debug_normal};
+    constexpr int kShared = (kGroupAgree - 1) / 2;
+    const int mine[kShared] = {first_pass, total_spp, c->width, c->height, c->max_bounces, c->debug_normal, shading_hash(c->shading)};
     int v[kGroupAgree] = {0};
-    for (int k = 0; k < 6; k++) { v[2 * k] = mine[k]; v[2 * k + 1] = -mine[k]; }
-    v[12] = -local;                                  // PT_E_* are negative: max over ranks of -status > 0 means some rank failed
+    for (int k = 0; k < kShared; k++) { v[2 * k] = mine[k]; v[2 * k + 1] = -mine[k]; }
+    v[kGroupAgree - 1] = -local;                                  // PT_E_* are negative: max over ranks of -status > 0 means some rank failed
     HIPCHK(c, hipMemcpyAsync(c->group_agree, v, sizeof v, hipMemcpyHostToDevice, c->stream));
     int nrc = r.AllReduce(c->group_agree, c->group_agree, kGroupAgree, kNcclInt32, kNcclMax, c->group_comm, c->stream);
     if (nrc) return fail(c, PT_E_HIP, "ncclAllReduce: %s", r.GetErrorString(nrc));
@@ -929,10 +1032,10 @@ int pt_group_render(pt_ctx *c, int first_pass, int total_spp)
     HIPCHK(c, hipMemcpyAsync(all, c->group_agree, sizeof all, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (local != PT_OK) return local;                // this rank's own message is already set (the others leave two lines below)
-    if (all[12] > 0) return fail(c, PT_E_STATE, "another rank of the group failed its checks (status %d); nothing was rendered", -all[12]);
+    if (all[kGroupAgree - 1] > 0) return fail(c, PT_E_STATE, "another rank of the group failed its checks (status %d); nothing was rendered", -all[kGroupAgree - 1]);
     // every rank sees the same (max, min) pairs, so either all of them return here or none does
-    static const char *what[] = {"first_pass", "total_spp", "width", "height", "max_bounces", "debug_normal"};
-    for (int k = 0; k < 6; k++)
+    static const char *what[kShared] = {"first_pass", "total_spp", "width", "height", "max_bounces", "debug_normal", "the shading parameters (hash)"};
+    for (int k = 0; k < kShared; k++)
         if (all[2 * k] != -all[2 * k + 1])
             return fail(c, PT_E_INVALID, "the ranks of the group disagree on %s (here %d, over the group %d..%d); nothing was rendered", what[k], mine[k], -all[2 * k + 1], all[2 * k]);
     // contiguous, balanced split (the first total % world ranks take one pass more): path_tracer_amd/distributed.py pass_range

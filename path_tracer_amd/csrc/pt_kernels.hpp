@@ -37,7 +37,30 @@ constexpr int kNumCounters = 18;
 constexpr int kBvhStack = kBvhMaxDepth + 1;   // per-lane traversal stack entries (one extra: the sphere tree's root under the mesh tree)
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
+// PtShadingParams (include/pt_hip.h: the literals in which rt.frag differs from rt.comp) as the kernels take them:
+// wave-uniform kernel arguments, filled by shading_of() in pt_api.hip.
+struct Shading {
+    float hit_limit;          // HIT_LIMIT (rt.comp:10)
+    float origin_offset;      // rt.comp:305
+    float jitter_scale;       // rt.comp:332
+    float sky[3];             // skyColor (rt.comp:25): multiplies rayColor at a miss (rt.comp:316)
+    float sky_emit[3];        // skyColor * skyIntensity (rt.comp:315), multiplied on the host in float32
+    float box_slack;          // traversal: a box whose exit lies before this (negative) t holds nothing that counts as hit
+    float pix_off;            // 0: integer texel coordinates (rt.comp:12) | 0.5: pixel centres (rt.frag:14)
+    int flags;                // kSh* bits: where the two shaders differ in the form of an expression, not in a literal
+};
+enum : int {
+    kShN1One = 1,             // FresnelReflectAmount's n1 = 1.0 (rt.frag:283) instead of ior (rt.comp:283)
+    kShTwoDraws = 2,          // second RandomInHemisphere for the refraction branch (rt.frag:295)
+    kShSqrtOut = 4,           // sqrt(incoming / bounces) (rt.frag:320)
+    kShSumXyz = 8,            // sphere test: squared lengths summed (x*x + y*y) + z*z (rt.frag:89-91)
+    kShTraceMesh = 16,        // the mesh is traced behind the root-AABB gate (rt.comp:213-218; not in rt.frag:207-216)
+    kShDefault = kShTraceMesh // rt.comp
+};
+constexpr float kBoxSlack = -1e-4f;   // Shading::box_slack for rt.comp's hit limit
+
 struct SceneView {
+    Shading sh;               // how it is to be shaded (not scene data; here because every intersection routine takes the view)
     const float *mesh_soa;    // [n_chunks][9][kChunk]; component c of triangle (chunk, lane, slot) at c*kChunk + slot*64 + lane
     const float4 *mesh_p1;    // per mesh triangle: xyz = p1, w = bits(materialIndex)
     const float4 *mesh_e1;    // xyz = p2 - p1
@@ -219,7 +242,7 @@ struct LdsStore {
 
 // One broadcast ray against the SLOTS triangles this lane holds: local closest hit (lt, ls).
 template <int SLOTS, bool FAST, class Store>
-__device__ __forceinline__ void test_slots(const Store &st, v3 ro, v3 rd, float &lt, int &ls, bool &bad)
+__device__ __forceinline__ void test_slots(const Store &st, v3 ro, v3 rd, float &lt, int &ls, bool &bad, float hl)
 {
     lt = kInfinity;
     ls = 0;
@@ -228,7 +251,7 @@ __device__ __forceinline__ void test_slots(const Store &st, v3 ro, v3 rd, float 
         v3 p1, e1, e2;
         st.get(s, p1, e1, e2);
         float t, det;
-        bool has = hit_triangle_t<FAST>(p1, e1, e2, ro, rd, t, det, bad);
+        bool has = hit_triangle_t<FAST>(p1, e1, e2, ro, rd, t, det, bad, hl);
         if (has && t < lt) { lt = t; ls = s; }
         // keep the slots (nearly) sequential: interleaving 11 independent tests costs ~20 live VGPRs each
         if ((s + 1) % PT_SLOT_GROUP == 0) __builtin_amdgcn_sched_barrier(PT_SCHED_MASK);
@@ -254,10 +277,10 @@ __device__ __forceinline__ void mesh_closest(const SceneView &sc, Store &st, int
             int ls;
             bool bad = false;
 #if PT_FAST_RCP
-            test_slots<SLOTS, true>(st, ro, rd, lt, ls, bad);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) test_slots<SLOTS, false>(st, ro, rd, lt, ls, bad);
+            test_slots<SLOTS, true>(st, ro, rd, lt, ls, bad, sc.sh.hit_limit);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) test_slots<SLOTS, false>(st, ro, rd, lt, ls, bad, sc.sh.hit_limit);
 #else
-            test_slots<SLOTS, false>(st, ro, rd, lt, ls, bad);
+            test_slots<SLOTS, false>(st, ro, rd, lt, ls, bad, sc.sh.hit_limit);
 #endif
             const float tmin = readlane_f(wave_min_to_lane63(lt), 63);
             if (tmin < kInfinity) {
@@ -308,6 +331,7 @@ struct BvhStore {
     const float4 *sph;
     __device__ __forceinline__ void sphere(int j, float4 &cr, int &index) const { cr = sph[2 * j]; index = __float_as_int(sph[2 * j + 1].x); }
     lds_cf4v *scene = nullptr;      // wave-uniform operands staged in LDS (stage_scene_lds), null: read through scalar loads
+    lds_cf4v *shade = nullptr;      // the kShadeLdsVecs shading vectors in front of them (always staged)
 };
 // ... or copied into the workgroup's LDS (meshes whose nodes + triangles fit beside the stacks): a dependent node
 // fetch then costs ~100 cycles instead of an L2 round trip, and the traversal is a chain of them.
@@ -332,6 +356,7 @@ struct BvhLdsStore {
     lds_cf4v *sph;
     __device__ __forceinline__ void sphere(int j, float4 &cr, int &index) const { cr = f4(sph[2 * j]); index = __float_as_int(sph[2 * j + 1].x); }
     lds_cf4v *scene = nullptr;      // wave-uniform operands staged in LDS (stage_scene_lds), null: read through scalar loads
+    lds_cf4v *shade = nullptr;      // the kShadeLdsVecs shading vectors in front of them (always staged)
 };
 
 __device__ __forceinline__ void slab_test(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, v3 olo, v3 ohi, v3 inv,
@@ -408,8 +433,8 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, Store &st, bool
                 st.tri(first + i, p1, e1, e2);
                 float t, det;
                 bool bad = false;
-                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, bad);
-                if (__builtin_expect(bad, 0)) has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, bad, sc.sh.hit_limit);
+                if (__builtin_expect(bad, 0)) has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
                 const int id = __float_as_int(p1.w);
                 n_tests++;
                 if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
@@ -432,14 +457,14 @@ __device__ __forceinline__ void scene_closest(const SceneView &sc, v3 o, v3 d, f
     for (int i = 0; i < sc.n_tris; i++) {
         const float4 p1 = uniform_load(sc.tri_p1, i), e1 = uniform_load(sc.tri_e1, i), e2 = uniform_load(sc.tri_e2, i);
         float t, det;
-        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
     }
     if (!with_spheres) return;
     for (int i = 0; i < sc.n_sph; i++) {
         const float4 s = uniform_load(sc.sph, i);
         float t; bool front;
-        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front, sc.sh.hit_limit, (sc.sh.flags & kShSumXyz) != 0);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
     }
 }
@@ -453,7 +478,7 @@ __device__ __forceinline__ void finish_hit(const SceneView &sc, v3 o, v3 d, Hit 
         const int i = h.id - sc.n_mesh - sc.n_tris;
         const float4 s = sc.sph[i];
         float t; bool front;
-        hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front, sc.sh.hit_limit, (sc.sh.flags & kShSumXyz) != 0);
         v3 point = o + d * h.t;                                         // rt.comp:144
         v3 n = normalize(point - V(s.x, s.y, s.z));
         h.front = front;
@@ -468,7 +493,7 @@ __device__ __forceinline__ void finish_hit(const SceneView &sc, v3 o, v3 d, Hit 
             p1 = sc.mesh_p1[h.id]; e1 = sc.mesh_e1[h.id]; e2 = sc.mesh_e2[h.id]; nr = sc.mesh_nrm[h.id];
         }
         float t, det;
-        hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         v3 n = V(nr.x, nr.y, nr.z);
         h.front = !(det < 0.0f);                                        // rt.comp:174
         h.normal = det < 0.0f ? n : -n;                                 // rt.comp:177
@@ -477,31 +502,32 @@ __device__ __forceinline__ void finish_hit(const SceneView &sc, v3 o, v3 d, Hit 
 }
 
 // The same two steps for the traversal kernels, from the unified table (one base pointer, one cache line per record).
-__device__ __forceinline__ void scene_closest_tab(const SceneView &sc, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres)
+// xyz: the sphere test's summation order (kShSumXyz), passed in so that a kernel built for rt.comp's forms carries no select
+__device__ __forceinline__ void scene_closest_tab(const SceneView &sc, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres, bool xyz)
 {
     for (int i = 0; i < sc.n_tris; i++) {
         const int rec = 4 * (sc.n_mesh + i);
         const float4 p1 = uniform_load(sc.prim_tab, rec), e1 = uniform_load(sc.prim_tab, rec + 1), e2 = uniform_load(sc.prim_tab, rec + 2);
         float t, det;
-        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
     }
     if (!with_spheres) return;
     for (int i = 0; i < sc.n_sph; i++) {
         const float4 s = uniform_load(sc.sph, i);
         float t; bool front;
-        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front, sc.sh.hit_limit, xyz);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
     }
 }
-__device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, Hit &h)
+__device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, Hit &h, bool xyz)
 {
     if (h.id < 0) return;
     if (h.id >= sc.n_mesh + sc.n_tris) {
         const int i = h.id - sc.n_mesh - sc.n_tris;
         const float4 s = sc.sph[i];
         float t; bool front;
-        hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front, sc.sh.hit_limit, xyz);
         v3 point = o + d * h.t;                                         // rt.comp:144
         v3 n = normalize(point - V(s.x, s.y, s.z));
         h.front = front;
@@ -511,7 +537,7 @@ __device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, 
         const float4 *r = sc.prim_tab + 4 * (size_t)h.id;
         const float4 p1 = r[0], e1 = r[1], e2 = r[2], nr = r[3];
         float t, det;
-        hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         v3 n = V(nr.x, nr.y, nr.z);
         h.front = !(det < 0.0f);                                        // rt.comp:174
         h.normal = det < 0.0f ? n : -n;                                 // rt.comp:177
@@ -529,7 +555,7 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int
     Hit h;
     h.id = -1; h.t = kInfinity; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
     bool gate = false;
-    if (alive && sc.n_mesh > 0)
+    if (alive && sc.n_mesh > 0 && (sc.sh.flags & kShTraceMesh))
         gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), o, d);
     const unsigned long long gate_mask = wave_ballot(gate);
     n_seg += __popcll(wave_ballot(alive));
@@ -551,19 +577,20 @@ __device__ __forceinline__ Hit calculate_ray(const SceneView &sc, Store &st, int
 }
 
 // rt.comp:326-333.  Returns the rng state after the six jitter draws.
-__device__ __forceinline__ uint32_t primary_ray(const FrameParams &fp, int x, int y, int pass, v3 &o, v3 &d)
+__device__ __forceinline__ uint32_t primary_ray(const FrameParams &fp, const Shading &sh, int x, int y, int pass, v3 &o, v3 &d)
 {
     const float W = (float)fp.width, H = (float)fp.height;
-    const float vx = (float)x / W, vy = (float)y / H;
+    const float fx = (float)x + sh.pix_off, fy = (float)y + sh.pix_off;       // rt.comp:12 | rt.frag:14 (x + 0.5 is exact)
+    const float vx = fx / W, vy = fy / H;
     const float px = ((vx - 0.5f) * W) / H;            // rt.comp:14,17
     const float py = vy - 0.5f;
-    uint32_t state = (uint32_t)pass * pixel_index(x, y, W, H);          // rt.comp:327
+    uint32_t state = (uint32_t)pass * pixel_index(fx, fy, W, H);        // rt.comp:327
     // `RandomDirection(s) * 0.00025` (rt.comp:332): the reference's compiler folds the constant into the
     // normalize as (v * 0.00025) * (1/sqrt(dot(v,v)))
     float gx = random_value_nd(state), gy = random_value_nd(state), gz = random_value_nd(state);
     v3 g = V(gx, gy, gz);
     float gr = 1.0f / sqrtf(dot(g, g));
-    v3 jit = (g * 0.00025f) * gr;
+    v3 jit = (g * sh.jitter_scale) * gr;
     const float X = -px + jit.x, Y = py + jit.y;
     const float *m = fp.iv;   // c0 = m[0..2], c1 = m[3..5], c2 = m[6..8]
     // mat4 * vec4(X, Y, 1, 0) -> (c0*X + c2) + c1*Y
@@ -583,13 +610,14 @@ __device__ __forceinline__ void shade_hit(const SceneView &sc, const Hit &h, Pat
     v3 o = ps.o + ps.d * h.t;                                           // hitPoint (rt.comp:175 / :144)
     const float ior = h.front ? (1.0f / m_ior) : m_ior;
     const bool is_spec = m->specularChance > random_value(ps.rng);
-    const float fres = fresnel_reflect_amount(ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);
+    const float fres = fresnel_reflect_amount((sc.sh.flags & kShN1One) ? 1.0f : ior, m_ior, h.normal, ps.d, 1.0f - m->refractionAmount);   // rt.comp:283 | rt.frag:283
     const bool is_refr = fres < random_value(ps.rng);
     const v3 hemi = random_in_hemisphere(h.normal, ps.rng);
+    const v3 hemi2 = (sc.sh.flags & kShTwoDraws) ? random_in_hemisphere(h.normal, ps.rng) : hemi;     // rt.frag:295
     const v3 a = mix3(hemi, reflect3(ps.d, h.normal), is_spec ? m_spec_smooth : m_smooth);
-    const v3 b = mix3(-hemi, refract3(ps.d, h.normal, ior), m_smooth);
+    const v3 b = mix3(-hemi2, refract3(ps.d, h.normal, ior), m_smooth);
     ps.d = normalize(select3(is_refr, b, a));
-    ps.o = o + ps.d * 0.0002f;                                          // rt.comp:305
+    ps.o = o + ps.d * sc.sh.origin_offset;                              // rt.comp:305
     const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
     const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
     ps.emitted = ps.emitted + V(m->emissionColor[0], m->emissionColor[1], m->emissionColor[2]) * m->emissionStrength;
@@ -651,7 +679,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
             n_iter++;
             PT_TICK(c0);
             if (alive && fresh) {
-                ps.rng = primary_ray(fp, x, y, fp.first_pass + k, ps.o, ps.d);
+                ps.rng = primary_ray(fp, sc.sh, x, y, fp.first_pass + k, ps.o, ps.d);
                 ps.ray_color = V(1, 1, 1); ps.incoming = V(0, 0, 0); ps.emitted = V(0, 0, 0); ps.bounces = 0;
                 fresh = false;
             }
@@ -672,12 +700,14 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
                         done = ps.bounces >= max_bounces;
                     } else {
                         ps.bounces++;
-                        ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);  // skyColor * skyIntensity (rt.comp:315)
-                        ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
+                        ps.emitted = ps.emitted + V(sc.sh.sky_emit[0], sc.sh.sky_emit[1], sc.sh.sky_emit[2]);   // skyColor * skyIntensity (rt.comp:315)
+                        ps.ray_color = ps.ray_color * V(sc.sh.sky[0], sc.sh.sky[1], sc.sh.sky[2]);              // rt.comp:316
+                        ps.incoming = ps.incoming + ps.emitted * ps.ray_color;
                         done = true;                                    // break (rt.comp:318)
                     }
                     const float nb = (float)ps.bounces;
                     colour = V(ps.incoming.x / nb, ps.incoming.y / nb, ps.incoming.z / nb);   // rt.comp:322
+                    if (sc.sh.flags & kShSqrtOut) colour = V(sqrtf(colour.x), sqrtf(colour.y), sqrtf(colour.z));   // rt.frag:320
                 }
                 if (done) {
                     rad[(size_t)k * plane] = Rgb{colour.x, colour.y, colour.z};
@@ -720,10 +750,21 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 // these few values in LDS once per workgroup and read them back with ds_read_b128 at a wave-uniform address (a broadcast:
 // no bank conflict, no VALU slot): they arrive in VGPRs.  Layout (float4): [0, 3n) scene triangles (p1 | -, e1, e2),
 // then bmin, bmax, (iv0 iv1 iv2 iv3), (iv4 iv5 iv6 iv7), (iv8 cam.x cam.y cam.z).
+// In front of them, always: the shading parameters that are read once per path or per pixel (sky, jitter scale, origin
+// offset, pixel-centre offset) -- as kernel arguments they would sit in SGPRs through the traversal loops, where the
+// kernel already spills; here they cost one ds_read at the point of use.  (sky | jitter_scale), (sky_emit | origin_offset),
+// (pix_off, -, -, -).
+constexpr int kShadeLdsVecs = 3;
 constexpr int kSceneLdsTris = 16;                                  // scenes with more triangles keep the scalar path
-constexpr int kSceneLdsVecs = 3 * kSceneLdsTris + 5;
+constexpr int kSceneLdsVecs = kShadeLdsVecs + 3 * kSceneLdsTris + 5;
 __device__ __forceinline__ bool stage_scene_lds(float4 *dst, const SceneView &sc, const FrameParams &fp, int tid, int n_threads)
 {
+    if (tid == 0) {
+        dst[0] = make_float4(sc.sh.sky[0], sc.sh.sky[1], sc.sh.sky[2], sc.sh.jitter_scale);
+        dst[1] = make_float4(sc.sh.sky_emit[0], sc.sh.sky_emit[1], sc.sh.sky_emit[2], sc.sh.origin_offset);
+        dst[2] = make_float4(sc.sh.pix_off, 0.0f, 0.0f, 0.0f);
+    }
+    dst += kShadeLdsVecs;
     if (sc.n_tris > kSceneLdsTris) return false;
     for (int i = tid; i < 3 * sc.n_tris; i += n_threads) dst[i] = sc.prim_tab[4 * (sc.n_mesh + i / 3) + i % 3];
     if (tid == 0) {
@@ -739,19 +780,19 @@ __device__ __forceinline__ bool stage_scene_lds(float4 *dst, const SceneView &sc
 __device__ __forceinline__ float4 lds_f4(lds_cf4v *p, int i) { const f4v v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
 
 // scene_closest_tab with the triangle records read from the LDS copy (VGPR operands); spheres as before
-__device__ __forceinline__ void scene_closest_lds(const SceneView &sc, lds_cf4v *scene, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres)
+__device__ __forceinline__ void scene_closest_lds(const SceneView &sc, lds_cf4v *scene, v3 o, v3 d, float &best_t, int &best_id, bool with_spheres, bool xyz)
 {
     for (int i = 0; i < sc.n_tris; i++) {
         const float4 p1 = lds_f4(scene, 3 * i), e1 = lds_f4(scene, 3 * i + 1), e2 = lds_f4(scene, 3 * i + 2);
         float t, det;
-        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+        bool has = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + i; }
     }
     if (!with_spheres) return;
     for (int i = 0; i < sc.n_sph; i++) {
         const float4 s = uniform_load(sc.sph, i);
         float t; bool front;
-        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front);
+        bool has = hit_sphere(V(s.x, s.y, s.z), s.w, o, d, t, front, sc.sh.hit_limit, xyz);
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
     }
 }
@@ -776,9 +817,17 @@ constexpr int kTravDone = (int)0x80000000;      // traversal position of a lane 
 // SPH: the scene has a sphere tree (compile-time, so scenes without spheres carry none of its code or registers).
 // SHORT: launches of a few passes (interactive use): items are dealt round-robin to the waves instead of pulled from the
 // queue, every item covers all passes, and the lane keeps the running mean in registers (no workspace, no pt_accumulate).
-template <bool SPH, bool SHORT, class Store>
+// GEN: everything in Shading is read from the arguments.  Otherwise (the kernels pin these fields of their by-value copy
+// before calling, so the compiler folds them) the kSh* flags -- the places where rt.frag differs from rt.comp in the FORM
+// of an expression -- and the hit limit with its box slack are rt.comp's at compile time: the flags' selects and branches
+// vanish, and the two limits, which are compared in every step of the traversal loop, do not take two more SGPRs there
+// (measured: +0.10 ms of 6.2 on config 2, the loop already spills).  The other numeric parameters are arguments either
+// way.  launch_trace picks GEN whenever flags, hit limit or slack differ from rt.comp's.
+template <bool SPH, bool SHORT, bool GEN, class Store>
 __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const FrameParams &fp, Store &st, int lane)
 {
+    const int sh_flags = sc.sh.flags;
+    const bool sh_xyz = (sh_flags & kShSumXyz) != 0;
     const int sph_root = SPH ? sc.sph_root : -1;
     const int max_bounces = fp.debug_normal ? 1 : fp.max_bounces;      // rt.comp:23
     const unsigned plane = (unsigned)(fp.width * fp.height);          // sample index k * plane + pixel < 2^32 (launch_trace bounds the batch)
@@ -859,9 +908,11 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     if (state == S_DEAD && rank < room) {
                         x = t_x0 + t_next + rank; y = t_y; k = t_k0; k_end = t_kend;
                         const float W = (float)fp.width, H = (float)fp.height;
-                        pix_seed = pixel_index(x, y, W, H);
-                        pix_x = ((((float)x / W) - 0.5f) * W) / H;      // rt.comp:14,17
-                        pix_y = ((float)y / H) - 0.5f;
+                        const float pix_off = lds_f4(st.shade, 2).x;
+                        const float fx = (float)x + pix_off, fy = (float)y + pix_off;   // rt.comp:12 | rt.frag:14 (x + 0.5 is exact)
+                        pix_seed = pixel_index(fx, fy, W, H);
+                        pix_x = (((fx / W) - 0.5f) * W) / H;            // rt.comp:14,17
+                        pix_y = (fy / H) - 0.5f;
                         if (SHORT) {
                             const float4 prev = reinterpret_cast<const float4 *>(fp.accum)[(size_t)y * fp.width + x];
                             acc = V(prev.x, prev.y, prev.z); acc_w = prev.w;
@@ -911,7 +962,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             slab_test_fma(b.z, b.w, c.x, c.y, c.z, c.w, nlo, nhi, inv, r0, r1);
                             const float lim = fmaf(best_t, 1.001f, delta);
                             // a sphere counts as hit down to t = -HIT_LIMIT (rt.comp:146), hence the slack on the far side
-                            const bool hl = l0 <= l1 && l1 >= -1e-4f && l0 <= lim, hr = r0 <= r1 && r1 >= -1e-4f && r0 <= lim;
+                            const bool hl = l0 <= l1 && l1 >= sc.sh.box_slack && l0 <= lim, hr = r0 <= r1 && r1 >= sc.sh.box_slack && r0 <= lim;
                             const bool take_left = hl && (!hr || l0 <= r0);
                             const int near = take_left ? kl : kr, far = take_left ? kr : kl;
                             stk[sp * kWave] = (unsigned)far;            // stays on the stack only if both children are hit
@@ -931,7 +982,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                                 int si;
                                 st.sphere(first, cr, si);
                                 float t; bool front;
-                                const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front);
+                                const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front, sc.sh.hit_limit, sh_xyz);
                                 const int id = sc.n_mesh + sc.n_tris + si;
                                 n_sph_tests++;
                                 if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
@@ -944,11 +995,11 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                                 st.tri(two ? first + 1 : first, q1, f1, f2);
                                 float t, det, t2, det2;
                                 bool bad = false;
-                                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad);
-                                bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad);
+                                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad, sc.sh.hit_limit);
+                                bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad, sc.sh.hit_limit);
                                 if (__builtin_expect(bad, 0)) {
-                                    has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det);
-                                    has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2);
+                                    has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, sc.sh.hit_limit);
+                                    has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, sc.sh.hit_limit);
                                 }
                                 const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
                                 n_bvh_tests += two ? 2 : 1;
@@ -985,7 +1036,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 if (state == S_READY) {
                     Hit h;
                     h.id = best_id; h.t = best_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
-                    finish_hit_tab(sc, ps.o, ps.d, h);
+                    finish_hit_tab(sc, ps.o, ps.d, h, sh_xyz);
                     const bool hit = h.id >= 0 && h.t < kInfinity;
                     bool done = true;
                     v3 colour;
@@ -1002,7 +1053,9 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             const float4 mf = sc.mat_fres[h.mat];
                             const float ior = h.front ? mf.x : m_ior;
                             const bool is_spec = m->specularChance > random_value(ps.rng);
-                            const float fres = fresnel_reflect_amount_pre(h.front ? mf.y : mf.w, ior > m_ior, mf.z, h.normal, ps.d, 1.0f - m->refractionAmount);
+                            // n1 = ior (rt.comp:283) or 1.0 (rt.frag:283): the table follows the mode (pt_api.hip fresnel_table)
+                            const float fres = fresnel_reflect_amount_pre(h.front ? mf.y : mf.w, ((sh_flags & kShN1One) ? 1.0f : ior) > m_ior, h.front ? mf.z : mf.x,
+                                                                          h.normal, ps.d, 1.0f - m->refractionAmount);
                             const bool is_refr = fres < random_value(ps.rng);
                             const v3 base = V(m->baseColor[0], m->baseColor[1], m->baseColor[2]);
                             const v3 spec = V(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
@@ -1020,11 +1073,14 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             }
                         } else {
                             ps.bounces++;
-                            ps.emitted = ps.emitted + V(0.5f, 0.5f, 0.5f);  // skyColor * skyIntensity (rt.comp:315)
-                            ps.incoming = ps.incoming + ps.emitted * ps.ray_color;   // rayColor *= vec3(1) is exact
+                            const float4 sky = lds_f4(st.shade, 0), sky_emit = lds_f4(st.shade, 1);
+                            ps.emitted = ps.emitted + V(sky_emit.x, sky_emit.y, sky_emit.z);    // skyColor * skyIntensity (rt.comp:315)
+                            ps.ray_color = ps.ray_color * V(sky.x, sky.y, sky.z);               // rt.comp:316
+                            ps.incoming = ps.incoming + ps.emitted * ps.ray_color;
                         }
                         const float nb = (float)ps.bounces;
                         colour = div_small_int(ps.incoming, nb);   // rt.comp:322
+                        if (sh_flags & kShSqrtOut) colour = V(exact_sqrt(colour.x), exact_sqrt(colour.y), exact_sqrt(colour.z));   // rt.frag:320
                     }
                     if (done) {
                         if (SHORT) {
@@ -1092,7 +1148,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     const float gr = exact_rcp(exact_sqrt(dot(g, g)));        // normalize(v) = v * (1/sqrt(dot(v,v)))
                     if (fresh) {
                         // `RandomDirection(s) * 0.00025` (rt.comp:332) as the reference's compiler folds it
-                        const v3 jit = (g * 0.00025f) * gr;
+                        const v3 jit = (g * lds_f4(st.shade, 0).w) * gr;
                         const float X = -pix_x + jit.x, Y = pix_y + jit.y;
                         if (st.scene) {     // inverseView and the camera position from the LDS copy: VGPR operands
                             const float4 m0 = lds_f4(st.scene, 3 * sc.n_tris + 2), m1 = lds_f4(st.scene, 3 * sc.n_tris + 3), m2 = lds_f4(st.scene, 3 * sc.n_tris + 4);
@@ -1107,10 +1163,17 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     } else {
                         const v3 r = g * gr;
                         const v3 hemi = dot(r, nrm) > 0.0f ? r : -r;    // rt.comp:92-95
+                        v3 hemi2 = hemi;
+                        if (sh_flags & kShTwoDraws) {                        // rt.frag:295: the refraction branch draws its own direction
+                            const float hx = random_value_nd(ps.rng), hy = random_value_nd(ps.rng), hz = random_value_nd(ps.rng);
+                            const v3 h2 = V(hx, hy, hz);
+                            const v3 r2 = h2 * exact_rcp(exact_sqrt(dot(h2, h2)));
+                            hemi2 = dot(r2, nrm) > 0.0f ? r2 : -r2;
+                        }
                         const v3 a = mix3(hemi, reflect3(ps.d, nrm), mix_a);
-                        const v3 b = mix3(-hemi, refract3(ps.d, nrm, eta), mix_b);
+                        const v3 b = mix3(-hemi2, refract3(ps.d, nrm, eta), mix_b);
                         ps.d = normalize(select3(refr, b, a));
-                        ps.o = hp + ps.d * 0.0002f;                     // rt.comp:305
+                        ps.o = hp + ps.d * lds_f4(st.shade, 1).w;       // rt.comp:305
                     }
                     state = S_TRACE;
                 }
@@ -1123,14 +1186,14 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 if (state == S_TRACE) {
                     s_t = kInfinity; s_id = -1;
                     if (st.scene) {     // root AABB and scene triangles from the LDS copy: VGPR operands
-                        if (sc.n_mesh > 0) {
+                        if (sc.n_mesh > 0 && (sh_flags & kShTraceMesh)) {
                             const float4 bn = lds_f4(st.scene, 3 * sc.n_tris), bx = lds_f4(st.scene, 3 * sc.n_tris + 1);
                             gate = hit_aabb(V(bn.x, bn.y, bn.z), V(bx.x, bx.y, bx.z), ps.o, ps.d);
                         }
-                        scene_closest_lds(sc, st.scene, ps.o, ps.d, s_t, s_id, sph_root < 0);
+                        scene_closest_lds(sc, st.scene, ps.o, ps.d, s_t, s_id, sph_root < 0, sh_xyz);
                     } else {
-                        if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
-                        scene_closest_tab(sc, ps.o, ps.d, s_t, s_id, sph_root < 0);
+                        if (sc.n_mesh > 0 && (sh_flags & kShTraceMesh)) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), ps.o, ps.d);
+                        scene_closest_tab(sc, ps.o, ps.d, s_t, s_id, sph_root < 0, sh_xyz);
                     }
                 }
                 n_seg += __popcll(wave_ballot(state == S_TRACE));
@@ -1222,20 +1285,20 @@ __global__ void __launch_bounds__(kWave) pt_tile_weights(SceneView sc, FramePara
     bool gate = false, other = false;
     if (x < fp.traced_width) {
         const float W = (float)fp.width, H = (float)fp.height;
-        const float X = -((((float)x / W - 0.5f) * W) / H), Y = (float)y / H - 0.5f;
+        const float X = -(((((float)x + sc.sh.pix_off) / W - 0.5f) * W) / H), Y = ((float)y + sc.sh.pix_off) / H - 0.5f;
         const float *m = fp.iv;
         const v3 d = normalize(V((m[0] * X + m[6]) + m[3] * Y, (m[1] * X + m[7]) + m[4] * Y, (m[2] * X + m[8]) + m[5] * Y));
         const v3 o = V(fp.cam[0], fp.cam[1], fp.cam[2]);
-        if (sc.n_mesh > 0) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), o, d);
+        if (sc.n_mesh > 0 && (sc.sh.flags & kShTraceMesh)) gate = hit_aabb(V(sc.bmin[0], sc.bmin[1], sc.bmin[2]), V(sc.bmax[0], sc.bmax[1], sc.bmax[2]), o, d);
         for (int i = 0; i < sc.n_tris && !other; i++) {
             const float4 p1 = sc.tri_p1[i], e1 = sc.tri_e1[i], e2 = sc.tri_e2[i];
             float t, det;
-            other = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det);
+            other = hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         }
         for (int i = 0; i < sc.n_sph && !other; i++) {
             const float4 sp = sc.sph[i];
             float t; bool front;
-            other = hit_sphere(V(sp.x, sp.y, sp.z), sp.w, o, d, t, front);
+            other = hit_sphere(V(sp.x, sp.y, sp.z), sp.w, o, d, t, front, sc.sh.hit_limit, (sc.sh.flags & kShSumXyz) != 0);
         }
     }
     const unsigned w = 65u * __popcll(wave_ballot(gate)) + __popcll(wave_ballot(other && !gate));
@@ -1284,25 +1347,27 @@ __global__ void __launch_bounds__(1024) pt_sort_tiles(const unsigned *weights, u
 
 // BVH traversal variant (any mesh size; the default for meshes of more than one register chunk): persistent 4-wave
 // workgroups, one ray per lane, per-lane traversal stack in LDS.
-template <bool SPH, bool SHORT>
+template <bool SPH, bool SHORT, bool GEN>
 __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc, FrameParams fp, int stack_entries)
 {
     extern __shared__ float4 bvh_lds_small[];    // wave-uniform operands (kSceneLdsVecs float4) | stacks: stack_entries x 4 B x 256 lanes
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhStore st;
+    if (!GEN) { sc.sh.hit_limit = kHitLimit; sc.sh.box_slack = kBoxSlack; sc.sh.flags = kShDefault; }     // see trace_items_body_bvh
     const bool staged = stage_scene_lds(bvh_lds_small, sc, fp, threadIdx.x, kLdsBlock);
     __syncthreads();
-    st.scene = staged ? (lds_cf4v *)bvh_lds_small : nullptr;
+    st.shade = (lds_cf4v *)bvh_lds_small;
+    st.scene = staged ? (lds_cf4v *)(bvh_lds_small + kShadeLdsVecs) : nullptr;
     st.stack = reinterpret_cast<unsigned *>(bvh_lds_small + kSceneLdsVecs) + wave * (stack_entries * kWave) + lane;
     st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
-    trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
+    trace_items_body_bvh<SPH, SHORT, GEN>(sc, fp, st, lane);
 }
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
 // LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | wave-uniform operands (kSceneLdsVecs x 16 B) | stacks
 // (stack_entries x 4 B x 512 lanes).
 constexpr int kBvhLdsBlock = 512;
-template <bool SPH, bool SHORT>
+template <bool SPH, bool SHORT, bool GEN>
 __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
 {
     extern __shared__ float4 bvh_lds[];
@@ -1312,14 +1377,16 @@ __global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneV
     for (int i = threadIdx.x; i < 4 * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
     for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
     for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
+    if (!GEN) { sc.sh.hit_limit = kHitLimit; sc.sh.box_slack = kBoxSlack; sc.sh.flags = kShDefault; }     // see trace_items_body_bvh
     const bool staged = stage_scene_lds(scene, sc, fp, threadIdx.x, kBvhLdsBlock);
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     BvhLdsStore st;
-    st.scene = staged ? (lds_cf4v *)scene : nullptr;
+    st.shade = (lds_cf4v *)scene;
+    st.scene = staged ? (lds_cf4v *)(scene + kShadeLdsVecs) : nullptr;
     st.stack = stack + wave * (stack_entries * kWave) + lane;
     st.nodes = (lds_cf4v *)nodes; st.tris = (lds_cf4v *)tris; st.sph = (lds_cf4v *)sph;
-    trace_items_body_bvh<SPH, SHORT>(sc, fp, st, lane);
+    trace_items_body_bvh<SPH, SHORT, GEN>(sc, fp, st, lane);
 }
 
 // rt.comp:337-339 over the passes of one batch, in pass order: accum = mix(accum, radiance(pass), 1/pass)
@@ -1375,7 +1442,7 @@ __device__ __forceinline__ void primary_hits_body(const SceneView &sc, const Fra
     const bool valid = x < fp.traced_width;
     v3 o = V(0, 0, 0), d = V(0, 0, 1);
     uint32_t state = 0;
-    if (valid) state = primary_ray(fp, x, y, fp.first_pass, o, d);
+    if (valid) state = primary_ray(fp, sc.sh, x, y, fp.first_pass, o, d);
     unsigned a = 0, b = 0, c = 0, e = 0, f = 0;
     unsigned long long g = 0;
     Hit h = calculate_ray<SLOTS>(sc, st, lane, valid, true, o, d, a, b, c, e, f, g);

@@ -46,7 +46,7 @@ __device__ __forceinline__ float maxps(float a, float b) { return a > b ? a : b;
 __device__ __forceinline__ v3 select3(bool c, v3 a, v3 b) { return V(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 
 constexpr float kInfinity = 10000000.0f;  // rt.comp:9
-constexpr float kHitLimit = 0.00001f;     // rt.comp:10
+constexpr float kHitLimit = 0.00001f;     // rt.comp:10 (the default of Shading::hit_limit)
 constexpr float kTwoPi = 6.28318530718f;  // rt.comp:8
 
 // ---- RNG (rt.comp:68-77) ----
@@ -204,10 +204,10 @@ __device__ __forceinline__ v3 random_in_hemisphere(v3 n, uint32_t &state)
     return dot(r, n) > 0.0f ? r : -r;
 }
 
-// rt.comp:12-13,16,326
-__device__ __forceinline__ uint32_t pixel_index(int x, int y, float W, float H)
+// rt.comp:12-13,16,326; fx, fy = the texel's integer coordinates (rt.comp:12) or its centre (gl_FragCoord, rt.frag:14)
+__device__ __forceinline__ uint32_t pixel_index(float fx, float fy, float W, float H)
 {
-    float vx = (float)x / W, vy = (float)y / H;
+    float vx = fx / W, vy = fy / H;
     float v = (vx / W) * 4294967296.0f + (vy / H) * 4294967296.0f;
     return (uint32_t)v;
 }
@@ -259,8 +259,9 @@ __device__ __forceinline__ float exact_rcp(float x)              // == 1.0f / x 
 // rt.comp:153-173 with e1 = p2-p1, e2 = p3-p1 precomputed (one rounding each, identical to the
 // shader's own subtraction).  Returns hasHit; t and det are always written.
 // FAST: reciprocal through fast_rcp_checked (sets `bad` when the caller must redo the test with FAST = false).
+// hl: HIT_LIMIT (rt.comp:10; 0 in rt.frag:166), wave-uniform.
 template <bool FAST>
-__device__ __forceinline__ bool hit_triangle_t(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out, bool &bad)
+__device__ __forceinline__ bool hit_triangle_t(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out, bool &bad, float hl)
 {
     v3 q = cross(d, e2);
     float det = dot(e1, q);
@@ -277,32 +278,35 @@ __device__ __forceinline__ bool hit_triangle_t(v3 p1, v3 e1, v3 e2, v3 o, v3 d, 
     // !(min(u,v) < 0) == !(u < 0) && !(v < 0) and !(max(u,u+v) > 1) == !(u > 1) && !(u+v > 1), NaNs included.
 #if PT_MINMAX
     const float lo = __builtin_fminf(u, v), hi = __builtin_fmaxf(u, u + v);
-    return t > kHitLimit && !(lo < 0.0f) && !(hi > 1.0f);
+    return t > hl && !(lo < 0.0f) && !(hi > 1.0f);
 #else
-    return t > kHitLimit && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
+    return t > hl && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f);
 #endif
 }
-__device__ __forceinline__ bool hit_triangle_ieee(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
+__device__ __forceinline__ bool hit_triangle_ieee(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out, float hl)
 {
     bool bad = false;
-    return hit_triangle_t<false>(p1, e1, e2, o, d, t_out, det_out, bad);
+    return hit_triangle_t<false>(p1, e1, e2, o, d, t_out, det_out, bad, hl);
 }
 // per-lane form: the fast reciprocal where it is exact, the IEEE divide for the lanes where it is not
-__device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out)
+__device__ __forceinline__ bool hit_triangle(v3 p1, v3 e1, v3 e2, v3 o, v3 d, float &t_out, float &det_out, float hl)
 {
     bool bad = false;
-    bool has = hit_triangle_t<true>(p1, e1, e2, o, d, t_out, det_out, bad);
-    if (__builtin_expect(bad, 0)) has = hit_triangle_ieee(p1, e1, e2, o, d, t_out, det_out);
+    bool has = hit_triangle_t<true>(p1, e1, e2, o, d, t_out, det_out, bad, hl);
+    if (__builtin_expect(bad, 0)) has = hit_triangle_ieee(p1, e1, e2, o, d, t_out, det_out, hl);
     return has;
 }
 
-// rt.comp:126-146; pow(length(v),2) folds to dot(v,v) and pow(r,2) to r*r in the reference's compiler
-__device__ __forceinline__ bool hit_sphere(v3 c, float radius, v3 o, v3 d, float &t_out, bool &front_out)
+// rt.comp:126-146; pow(length(v),2) folds to dot(v,v) and pow(r,2) to r*r in the reference's compiler.
+// hl: HIT_LIMIT; xyz: the squared lengths summed as rt.frag:89-91 writes them, (x*x + y*y) + z*z, instead of dot's
+// (z*z + y*y) + x*x -- both wave-uniform.
+__device__ __forceinline__ float length_squared_xyz(v3 v) { return (v.x * v.x + v.y * v.y) + v.z * v.z; }
+__device__ __forceinline__ bool hit_sphere(v3 c, float radius, v3 o, v3 d, float &t_out, bool &front_out, float hl, bool xyz)
 {
     v3 oc = o - c;
-    float a = dot(d, d);
+    float a = xyz ? length_squared_xyz(d) : dot(d, d);
     float hb = dot(oc, d);
-    float cc = dot(oc, oc) - radius * radius;
+    float cc = (xyz ? length_squared_xyz(oc) : dot(oc, oc)) - radius * radius;
     float disc = hb * hb - a * cc;
     float sq = exact_sqrt(disc);
     float t0 = (-hb - sq) / a;
@@ -310,7 +314,7 @@ __device__ __forceinline__ bool hit_sphere(v3 c, float radius, v3 o, v3 d, float
     bool front = t0 > 0.0f;
     t_out = front ? t0 : t1;
     front_out = front;
-    return t0 > kHitLimit || t1 > -kHitLimit;
+    return t0 > hl || t1 > -hl;
 }
 
 // rt.comp:235-254

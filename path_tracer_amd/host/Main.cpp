@@ -53,8 +53,8 @@ static void default_materials(Scene &scene)
 
 int main(int argc, char **argv)
 {
-    std::string mesh_path = "res/meshes/bunny1.obj", scene_name = "default", out_path, ppm_path;
-    int width = 1920, height = 1080, spp = 64, bounces = 8, device = 0;
+    std::string mesh_path = "res/meshes/bunny1.obj", scene_name = "default", out_path, ppm_path, shader_path = "res/shaders/rt.comp";
+    int width = 1920, height = 1080, spp = 64, bounces = 0, device = 0;
     bool debugNormal = false, batch = false, cam_given = false, print_camera = false;
     float cam[5] = {1.5f, 0.4f, 0.0f, 0.0f, 0.0f};
     int orbit_frames = 0; float orbit_deg = 0.0f;
@@ -65,6 +65,7 @@ int main(int argc, char **argv)
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", argv[i]); std::exit(2); } return argv[++i]; };
         if (!std::strcmp(argv[i], "--mesh")) mesh_path = next();
         else if (!std::strcmp(argv[i], "--scene")) scene_name = next();
+        else if (!std::strcmp(argv[i], "--shader")) shader_path = next();    // .../rt.comp (default) or .../rt.frag: which copy of the kernel to reproduce
         else if (!std::strcmp(argv[i], "--width")) width = std::atoi(next());
         else if (!std::strcmp(argv[i], "--height")) height = std::atoi(next());
         else if (!std::strcmp(argv[i], "--spp")) spp = std::atoi(next());
@@ -114,7 +115,8 @@ int main(int argc, char **argv)
     if (mixed && !cam_given) { cam[0] = 1.5f; cam[1] = 0.8f; cam[2] = 1.5f; cam[3] = 45.0f; cam[4] = 20.0f; }
 
     if (Renderer::Init(width, height, device)) return 1;
-    ComputeProgram computeProgram("rt");
+    ComputeProgram computeProgram(shader_path.c_str());
+    if (bounces <= 0) bounces = computeProgram.legacy() ? 12 : 8;       // rt.frag:337 | this driver's default
     ShaderProgram computeAccumProgram;
 
     default_materials(Renderer::scene);

@@ -7,6 +7,16 @@
 
 #include "Renderer.h"
 
+ComputeProgram::ComputeProgram(const char *filepath) : path(filepath ? filepath : "")
+{
+    const std::string legacyName = "rt.frag";
+    isLegacy = path.size() >= legacyName.size() && path.compare(path.size() - legacyName.size(), legacyName.size(), legacyName) == 0;
+    if (!Renderer::ctx) return;                     // nothing to configure yet (the defaults are rt.comp's)
+    PtShadingParams prm;
+    if (Renderer::Check(pt_shading_preset(&prm, isLegacy ? 1 : 0), "pt_shading_preset"))
+        Renderer::Check(pt_set_shading_params(Renderer::ctx, &prm), "pt_set_shading_params");
+}
+
 void ComputeProgram::SetUniform1i(const char *uName, int i)
 {
     if (!std::strcmp(uName, "currAccumPass")) currAccumPass = i;

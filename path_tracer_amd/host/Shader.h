@@ -8,7 +8,11 @@
 #include "Camera.h"
 
 struct ComputeProgram {
-    explicit ComputeProgram(const char *filepath = "") : path(filepath) {}
+    // The reference compiles the file it is given (src/Shader.cpp:41-70).  Here the file NAME selects which of the reference's
+    // two copies of the kernel the same HIP kernels reproduce: ".../rt.frag" -> the legacy literals (pt_shading_preset 1,
+    // SURVEY App. B), anything else -> rt.comp's (preset 0).  Call after Renderer::Init.
+    explicit ComputeProgram(const char *filepath = "");
+    bool legacy() const { return isLegacy; }
     void Use() {}
     void Unuse() {}
     void SetUniform1i(const char *uName, int i);     // "currAccumPass" (remembered), "debugNormal", "maxBounces"
@@ -17,6 +21,7 @@ struct ComputeProgram {
     int currAccumPass = 0;
 private:
     std::string path;
+    bool isLegacy = false;
 };
 
 struct ShaderProgram {

@@ -67,6 +67,18 @@ def test_pt_main_mixed_scene(tmp_path, meta):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [False, True])
+def test_pt_main_legacy_shader_name_selects_the_rt_frag_literals(tmp_path, meta, batch):
+    """ComputeProgram("res/shaders/rt.frag"): the image must be what rt.frag itself draws (12 bounces, no mesh, sqrt output ...)"""
+    obj, out = tmp_path / "bunny1.obj", tmp_path / "accum.f32"
+    _write_obj(obj)
+    subprocess.run([PT_MAIN, "--mesh", str(obj), "--scene", "mixed", "--shader", "res/shaders/rt.frag", "--width", "640", "--height", "360",
+                    "--spp", "4", "--out", str(out)] + (["--batch"] if batch else []), check=True, capture_output=True, timeout=120)
+    img = np.fromfile(out, np.float32).reshape(360, 640, 4)
+    assert crc(img[:, :, :3]) == meta["radiance_frag_mixed_b12_640x360"]["crc_mean4"]
+
+
+@pytest.mark.gpu
 def test_pt_main_scripted_camera_loop(tmp_path):
     """the interactive loop's stand-in (src/Main.cpp:108-150): the camera moves every frame, each frame restarts the
     accumulation (pt_reset) and renders 2 passes with the short-launch kernels; the last frame must be the image a fresh
