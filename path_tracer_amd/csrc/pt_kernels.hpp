@@ -811,6 +811,16 @@ __device__ __forceinline__ void scene_closest_lds(const SceneView &sc, lds_cf4v 
 // traversal runs with most lanes busy instead of at the occupancy of whichever iteration a ray happened to be born in.
 // Scheduling only: a sample is a pure function of (pixel, pass); mesh-before-scene tie order is kept by the merge rule
 // in `finish`: a scene primitive wins only with a strictly smaller t (rt.comp:213-230 scans the mesh first).
+// (t, id) < (best_t, best_id) in lexicographic order -- what the reference's in-order strict `<` scan keeps -- without
+// short-circuit evaluation, so that the update around it compiles to selects, not to a nest of exec-mask branches (16
+// instructions and three branches per triangle before; config 2 kernel 6.23 -> 6.14 ms).  Not as one integer comparison
+// of the bit patterns: a sphere counts as hit down to t1 = -HIT_LIMIT (rt.comp:142), so t can be negative or -0 (tried:
+// 46 pixels of config 5 differed).
+__device__ __forceinline__ bool closer_hit(float t, int id, float best_t, int best_id)
+{
+    return (t < best_t) | ((t == best_t) & (id < best_id));
+}
+
 enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DIR = 5 };
 constexpr int kTravDone = (int)0x80000000;      // traversal position of a lane that is not traversing; also the bottom of every stack
 
@@ -985,7 +995,8 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                                 const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front, sc.sh.hit_limit, sh_xyz);
                                 const int id = sc.n_mesh + sc.n_tris + si;
                                 n_sph_tests++;
-                                if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
+                                const bool take = has & closer_hit(t, id, best_t, best_id);
+                                best_t = take ? t : best_t; best_id = take ? id : best_id;
                                 used = 1;
                             } else {
                                 // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
@@ -1003,8 +1014,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                                 }
                                 const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
                                 n_bvh_tests += two ? 2 : 1;
-                                if (has && (t < best_t || (t == best_t && id < best_id))) { best_t = t; best_id = id; }
-                                if (two && has2 && (t2 < best_t || (t2 == best_t && id2 < best_id))) { best_t = t2; best_id = id2; }
+                                const bool take = has & closer_hit(t, id, best_t, best_id);
+                                best_t = take ? t : best_t; best_id = take ? id : best_id;
+                                const bool take2 = (two & has2) & closer_hit(t2, id2, best_t, best_id);
+                                best_t = take2 ? t2 : best_t; best_id = take2 ? id2 : best_id;
                                 used = two ? 2 : 1;
                             }
                             // primitives left: the leaf code moves on by `used` (first += used, count -= used: ~code falls by
@@ -1017,12 +1030,11 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     const bool fin = new_cur == kTravDone && cur != kTravDone;      // popped the bottom of the stack
                     cur = new_cur;
                     if (wave_any(fin)) {
-                        if (fin) {
-                            // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
-                            // the lexicographic minimum of (t, canonical id)
-                            if (s_id >= 0 && (s_t < best_t || (s_t == best_t && s_id < best_id))) { best_t = s_t; best_id = s_id; }
-                            state = S_READY;
-                        }
+                        // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
+                        // the lexicographic minimum of (t, canonical id)
+                        const bool take = fin & (s_id >= 0) & closer_hit(s_t, s_id, best_t, best_id);
+                        best_t = take ? s_t : best_t; best_id = take ? s_id : best_id;
+                        state = fin ? S_READY : state;
                     }
                 }
             } else if (n_mesh) {

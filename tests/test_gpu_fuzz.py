@@ -125,6 +125,35 @@ def test_axis_parallel_rays_and_degenerate_triangles(capi):
     assert n_diff_pixels(ref, O.Oracle(sc, cam, W, H, B).render(1, SPP)) == 0
 
 
+@pytest.mark.parametrize("gap", [4e-6, 8e-6, 2e-5])
+def test_sphere_hits_at_negative_distance(capi, gap):
+    """HitSphere counts t1 > -HIT_LIMIT (rt.comp:142): a camera `gap` outside a sphere, looking AWAY from it, "hits" the
+    sphere at t = -gap..0 when gap < 1e-5 (the closest hit of all: t < 0), and the path continues from behind the camera.
+    A hit record that assumes t > 0 breaks here (it did: 46 pixels of config 5)."""
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-0.3, 0.3, (40, 3, 3)).astype(np.float32) + np.array([0, 0.4, 2.5], np.float32)
+    tris = S.triangles_from_points(pts, 1)
+    sc = S.Scene(materials=S.default_materials(), mesh=S.Mesh(tris, S.Mesh.gen_bounding_box(tris), 1))
+    sc.add_triangle((-50, 0, 50), (50, 0, 50), (0, 0, -50), 3)
+    sc.add_sphere((0.0, 1.0, 0.0), 1.0, 2)                           # glass; the camera sits just outside its +z pole
+    sc.add_sphere((0.0, 1.0, 0.0), 0.999999, 0)                      # a second shell: two negative distances to order
+    for k in range(6):
+        sc.add_sphere((0.5 * k - 1.2, 0.3, 3.0), 0.2, k % 5)
+    cam = S.Camera(position=np.array([0.0, 1.0, np.float32(1.0) + np.float32(gap)], np.float32), yaw=-90.0, pitch=0.0).UpdateView()   # looks along +z
+    W, H, B, SPP = 128, 72, 6, 3
+    want = O.Oracle(sc, cam, W, H, B)
+    ids, t, _, _ = want.primary_hits(1)
+    if gap < 1e-5:
+        assert (t[ids >= 0] < 0).sum() > 1000, "the case under test: primary hits at negative distance"
+    ref, _ = render(capi, sc, cam, W, H, B, SPP, 1)
+    for variant in (5, 6):
+        img, _ = render(capi, sc, cam, W, H, B, SPP, variant)
+        assert bits_equal(img, ref), (variant, n_diff_pixels(img, ref))
+    assert n_diff_pixels(ref, want.render(1, SPP)) == 0
+
+
 @pytest.mark.parametrize("axis", [0, 1, 2])
 def test_exactly_zero_direction_component_reaches_the_traversal(capi, axis):
     """An inverseView whose row `axis` is all zeros makes EVERY primary ray's direction component on that axis exactly

@@ -1,10 +1,16 @@
 #!/bin/bash
-# tools/ab.sh -- A/B of library variants x passes-per-item on the GPU box (same ABI, PT_HIP_LIB selects the build)
-for lib in "" $(ls path_tracer_amd/variants/*.so 2>/dev/null); do
-  for c in ${CHUNKS:-2 4 8}; do
-    for w in ${WAVES:-12}; do
-    r=$(PT_HIP_LIB=$lib timeout -k 10 200 python -u bench.py --steps 5 --warmup 2 --no-cpu-baseline --passes-per-item $c --waves-per-cu $w --variant ${VARIANT:-0} 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=d['roofline']['work_per_launch']; print('%.2f ms/step kernel %.2f ms frac %.3f iters %.3g balance %.3f primary/mesh %.3f' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], w.get('wave_iterations',0), d['roofline'].get('wave_balance',0), w.get('primary_mesh_segments',0)/max(1,w['mesh_segments'])))")
-    echo "lib=${lib:-default} chunk=$c waves=$w : $r"
-    done
+# A/B on one GPU box: the same bench through several builds of the library (PT_HIP_LIB; same ABI), interleaved twice.
+#   tools/ab.sh CONFIG LIB [LIB ...]     (LIB = path of a libpt_hip.so build; results: gpurun_out/ab_<name>.log)
+set -e
+cfg=$1; shift
+for round in 1 2; do
+  for lib in "$@"; do
+    name=$(basename $lib .so)
+    PT_HIP_LIB=$PWD/$lib timeout -k 10 150 python bench.py --config $cfg --steps 60 --no-extra > gpurun_out/ab_$name.log 2>&1
+    python - <<PY
+import json
+l=[x for x in open('gpurun_out/ab_$name.log') if x.startswith('{')][-1]; d=json.loads(l)
+print('$name', 'config $cfg', 'step', round(d['ms_per_step'],4), 'kernel', round(d['roofline']['kernel_ms'],4), 'parity', d.get('cpu_baseline',{}).get('parity_vs_oracle'), flush=True)
+PY
   done
 done
