@@ -182,7 +182,8 @@ int pt_last_render_ms(pt_ctx *ctx, float *ms, int *n_launches);
  * variant: 1 = brute force, mesh triangles resident in VGPRs (any mesh size), 2 / 3 / 4 = brute force, resident in a
  * workgroup-shared LDS image at 4 / 5 / 6 waves per SIMD (meshes of at most 704 triangles; default for those),
  * 5 = BVH traversal, one ray per lane, BVH in global memory (any mesh size), 6 = the same with the BVH staged into
- * LDS (default; falls back to 5 when nodes + triangles + stacks exceed 80 KB; see DESIGN.md for its exactness). */
+ * LDS (default): two 512-thread workgroups per CU with a copy each while trees + stacks fit in 80 KB, else one
+ * 1024-thread workgroup per CU sharing one copy (up to 158 KB), else 5; see DESIGN.md for its exactness. */
 int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes, int waves_per_cu, int variant);
 /* Scheduling options of the traversal kernels, per context, by name (experiments and tests; none changes a result, and
  * the library reads no environment variable).  value 0 = the built-in choice for the launch at hand where noted.
@@ -192,6 +193,8 @@ int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes
  *   "refill_min" (0 | 1..64) hand out new pixels once this many lanes are idle
  *   "ppi1_mul", "ppi2_mul"   passes per work item of scene-only / sky tiles, as multiples of the mesh tiles' (4, 8)
  *   "no_fused" (0 | 1)       1: short launches also go through the per-pass workspace + pt_accumulate
+ *   "wgs_per_cu" (0 | 1..8)  workgroups per CU of the LDS-resident traversal kernel
+ *   "lds_block" (0|512|1024) force its workgroup size (falls back to variant 5 if the trees do not fit that way)
  * Unknown names and values out of range return PT_E_INVALID. */
 int pt_set_option(pt_ctx *ctx, const char *name, int value);
 /* Host-only (no HIP device needed; for tests and tools): build the library's BVH over `tris` exactly as pt_upload_mesh

@@ -132,7 +132,7 @@ struct pt_ctx {
     PtShadingParams shading;          // pt_set_shading_params; pt_create fills in preset 0 (rt.comp)
     std::vector<float> h_ior;         // material.ior of the uploaded materials (the Fresnel table depends on shading.fresnel_n1_one)
     // scheduling options (pt_set_option; 0 = the built-in choice for the launch at hand)
-    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0, opt_wgs_per_cu = 0;
+    int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0, opt_wgs_per_cu = 0, opt_lds_block = 0;
 };
 
 namespace {
@@ -270,8 +270,14 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
 // (template arguments SPH, SHORT, GEN of pt_kernels.hpp), with the names rocprofv3 reports them under.
 struct BvhKernel { const void *fn; const char *name; };
 #define PT_BVH_ROW(K, S, F) { { (const void *)&K<S, F, false>, #K "<" #S ", " #F ", false>" }, { (const void *)&K<S, F, true>, #K "<" #S ", " #F ", true>" } }
-const BvhKernel kBvhLdsKernels[2][2][2] = { { PT_BVH_ROW(pt_trace_items_bvh_lds, false, false), PT_BVH_ROW(pt_trace_items_bvh_lds, false, true) },
-                                            { PT_BVH_ROW(pt_trace_items_bvh_lds, true, false), PT_BVH_ROW(pt_trace_items_bvh_lds, true, true) } };
+#define PT_BVH_LDS_ROW(S, F, B) { { (const void *)&pt_trace_items_bvh_lds<S, F, false, B>, "pt_trace_items_bvh_lds<" #S ", " #F ", false, " #B ">" }, \
+                                  { (const void *)&pt_trace_items_bvh_lds<S, F, true, B>, "pt_trace_items_bvh_lds<" #S ", " #F ", true, " #B ">" } }
+// ... and by [one 1024-thread workgroup per CU instead of two of 512] first
+const BvhKernel kBvhLdsKernels[2][2][2][2] = { { { PT_BVH_LDS_ROW(false, false, 512), PT_BVH_LDS_ROW(false, true, 512) },
+                                                 { PT_BVH_LDS_ROW(true, false, 512), PT_BVH_LDS_ROW(true, true, 512) } },
+                                               { { PT_BVH_LDS_ROW(false, false, 1024), PT_BVH_LDS_ROW(false, true, 1024) },
+                                                 { PT_BVH_LDS_ROW(true, false, 1024), PT_BVH_LDS_ROW(true, true, 1024) } } };
+#undef PT_BVH_LDS_ROW
 const BvhKernel kBvhKernels[2][2][2] = { { PT_BVH_ROW(pt_trace_items_bvh, false, false), PT_BVH_ROW(pt_trace_items_bvh, false, true) },
                                          { PT_BVH_ROW(pt_trace_items_bvh, true, false), PT_BVH_ROW(pt_trace_items_bvh, true, true) } };
 #undef PT_BVH_ROW
@@ -279,12 +285,22 @@ const BvhKernel kBvhKernels[2][2][2] = { { PT_BVH_ROW(pt_trace_items_bvh, false,
 // Per-lane stack entries beyond the trees' depth: the permanent bottom entry, the other tree's root (counted in bvh_depth), and
 // the free slot above the stack that every node visit writes unconditionally.
 constexpr int kBvhStackExtra = 3;
-// LDS the LDS-resident BVH kernel needs per 512-thread workgroup; two workgroups must fit in a CU's 160 KB.
-constexpr size_t kBvhLdsLimit = 80 * 1024;
-size_t bvh_lds_bytes(const pt_ctx *c)
+// LDS the LDS-resident BVH kernel needs per workgroup of `block` threads: two workgroups of 512 must fit in a CU's 160 KB,
+// or one of 1024 (a little is left for the runtime).
+constexpr size_t kBvhLdsLimit = 80 * 1024, kBvhLdsLimitWide = 158 * 1024;
+size_t bvh_lds_bytes(const pt_ctx *c, int block)
 {
     return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
-           + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * kBvhLdsBlock;
+           + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * (size_t)block;
+}
+// 512 when the trees fit twice per CU, else 1024 (one shared copy per CU), 0: not at all (variant 5 reads them from global memory)
+int bvh_lds_block(const pt_ctx *c)
+{
+    if (c->opt_lds_block == kBvhLdsBlock || c->opt_lds_block == kBvhLdsBlockWide)
+        return bvh_lds_bytes(c, c->opt_lds_block) <= (c->opt_lds_block == kBvhLdsBlock ? kBvhLdsLimit : kBvhLdsLimitWide) ? c->opt_lds_block : 0;
+    if (bvh_lds_bytes(c, kBvhLdsBlock) <= kBvhLdsLimit) return kBvhLdsBlock;
+    if (bvh_lds_bytes(c, kBvhLdsBlockWide) <= kBvhLdsLimitWide) return kBvhLdsBlockWide;
+    return 0;
 }
 
 // Concatenate the two trees' nodes (mesh first: its root is node 0; the sphere tree's child indices are shifted) and upload.
@@ -331,7 +347,7 @@ int pick_variant(const pt_ctx *c)
 {
     int variant = c->variant ? c->variant : PT_DEFAULT_VARIANT;
     if (variant >= 5 && !c->bvh_ok) variant = PT_DEFAULT_LDS_VARIANT;     // no mesh, or coordinates the builder refused
-    if (variant == 6 && bvh_lds_bytes(c) > kBvhLdsLimit) variant = 5;     // too large for two workgroups per CU
+    if (variant == 6 && bvh_lds_block(c) == 0) variant = 5;               // too large for a CU's LDS
 
     if (variant >= 2 && variant <= 4 && c->n_chunks != 1) variant = 1;    // the LDS image holds exactly one chunk
     return variant;
@@ -454,14 +470,16 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
             hipLaunchKernelGGL((pt_trace_items_lds<kSlots, 5>), dim3(grid), dim3(kLdsBlock), 0, c->stream, sv, fp);
             c->last_kernel = "pt_trace_items_lds<11, 5>";
         } else if (variant == 6) {
-            const unsigned grid = (unsigned)std::min<long long>((items + 7) / 8, (long long)c->n_cus * (c->opt_wgs_per_cu ? c->opt_wgs_per_cu : 2));
-            const size_t lds = bvh_lds_bytes(c);
-            const BvhKernel &bk = kBvhLdsKernels[c->sph_root >= 0][fused][generic_shading(sv.sh)];
+            const int block = bvh_lds_block(c), waves = block / kWave;         // pick_variant made sure it is not 0
+            const int per_cu = c->opt_wgs_per_cu ? c->opt_wgs_per_cu : (block == kBvhLdsBlock ? 2 : 1);
+            const unsigned grid = (unsigned)std::min<long long>((items + waves - 1) / waves, (long long)c->n_cus * per_cu);
+            const size_t lds = bvh_lds_bytes(c, block);
+            const BvhKernel &bk = kBvhLdsKernels[block == kBvhLdsBlockWide][c->sph_root >= 0][fused][generic_shading(sv.sh)];
             const void *kern = bk.fn;
             HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + kBvhStackExtra;
             void *args[] = {&sv, &fp, &n_nodes, &entries};
-            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(kBvhLdsBlock), args, lds, c->stream));
+            HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(block), args, lds, c->stream));
             c->last_kernel = bk.name;
         } else if (variant == 5) {
             // as many 4-wave workgroups per CU as their stacks leave room for (at most 4: 124 VGPRs)
@@ -1132,7 +1150,7 @@ int pt_set_option(pt_ctx *c, const char *name, int value)
     struct { const char *name; int *slot; int lo, hi; } opts[] = {
         {"park_high", &c->opt_park_high, 0, 64}, {"park_wait", &c->opt_park_wait, 0, 1 << 20}, {"refill_min", &c->opt_refill_min, 0, 64},
         {"park_exit", &c->opt_park_exit, 0, 8}, {"ppi1_mul", &c->opt_ppi1_mul, 1, 4096}, {"ppi2_mul", &c->opt_ppi2_mul, 1, 4096},
-        {"no_fused", &c->opt_no_fused, 0, 1}, {"wgs_per_cu", &c->opt_wgs_per_cu, 0, 8},
+        {"no_fused", &c->opt_no_fused, 0, 1}, {"wgs_per_cu", &c->opt_wgs_per_cu, 0, 8}, {"lds_block", &c->opt_lds_block, 0, 1024},
     };
     for (auto &o : opts)
         if (!std::strcmp(name, o.name)) {

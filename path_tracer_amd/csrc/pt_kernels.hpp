@@ -1378,10 +1378,14 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
 // LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | wave-uniform operands (kSceneLdsVecs x 16 B) | stacks
 // (stack_entries x 4 B x 512 lanes).
-constexpr int kBvhLdsBlock = 512;
-template <bool SPH, bool SHORT, bool GEN>
-__global__ void __launch_bounds__(kBvhLdsBlock, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
+// BLOCK = 512: two workgroups per CU, each with its own copy (trees + stacks up to 80 KB); BLOCK = 1024: ONE workgroup per
+// CU whose sixteen waves share one copy, for trees that do not fit twice (up to 160 KB with the stacks) -- the same four
+// waves per SIMD either way.
+constexpr int kBvhLdsBlock = 512, kBvhLdsBlockWide = 1024;
+template <bool SPH, bool SHORT, bool GEN, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 4) pt_trace_items_bvh_lds(SceneView sc, FrameParams fp, int n_nodes, int stack_entries)
 {
+    constexpr int kBvhLdsBlock = BLOCK;
     extern __shared__ float4 bvh_lds[];
     const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
     float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;

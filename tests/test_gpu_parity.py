@@ -501,3 +501,24 @@ def test_ragged_image_sizes_vs_oracle(capi, cameras, scenes, size, spp):
     assert np.all(got[th:, :, :] == 0) and np.all(got[:, tw:, :] == 0)
     r.close()
 
+
+
+def test_one_shared_lds_copy_per_cu_for_trees_that_do_not_fit_twice(capi, cameras, scenes):
+    """pt_trace_items_bvh_lds<..., 1024>: one 1024-thread workgroup per CU shares one LDS copy of the trees where two copies
+    (two 512-thread workgroups) do not fit -- the mixed scene's bunny + 145 spheres; forced on the default scene it must give
+    the image of the 512-thread kernel bit for bit"""
+    g = np.load(os.path.join(GOLD, "radiance_128x72.npz"))
+    r = make(capi, scenes["mixed"], cameras["mixed"], 128, 72, 16)
+    r.render(1, 16)
+    assert r.kernel_name().startswith("pt_trace_items_bvh_lds<") and r.kernel_name().endswith(", 1024>"), r.kernel_name()
+    assert n_diff_pixels(r.read_accum()[:, :, :3], g["mixed_b16_128x72_mean16"]) == 0
+    r.close()
+    imgs = {}
+    for block in (512, 1024):
+        r = make(capi, scenes["default"], cameras["bench"], 640, 360, 8)
+        r.set_option("lds_block", block)
+        r.render(1, 6)
+        assert r.kernel_name().endswith(f", {block}>"), r.kernel_name()
+        imgs[block] = r.read_accum()
+        r.close()
+    assert bits_equal(imgs[512], imgs[1024])
