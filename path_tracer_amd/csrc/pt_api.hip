@@ -248,6 +248,13 @@ SceneView scene_view(const pt_ctx *c)
     return s;
 }
 
+// tiles of 64 pixels in the traced area (pt_kernels.hpp tile_pixel)
+int tile_count(int width, int height)
+{
+    const int tw = (width / 8) * 8, rows = (height / 8) * 8;
+    return PT_TILE_8X8 ? (tw / 8) * (rows / 8) : ((tw + kWave - 1) / kWave) * rows;
+}
+
 FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_mode)
 {
     FrameParams f;
@@ -259,7 +266,7 @@ FrameParams frame_params(const pt_ctx *c, int first_pass, int n_passes, int sum_
     f.first_pass = first_pass; f.n_passes = n_passes; f.sum_mode = sum_mode;
     f.chunk = c->chunk_passes;
     f.traced_width = (c->width / 8) * 8; f.rows = (c->height / 8) * 8;
-    f.x_blocks = (f.traced_width + kWave - 1) / kWave;
+    f.x_blocks = PT_TILE_8X8 ? f.traced_width / 8 : (f.traced_width + kWave - 1) / kWave;
     f.accum = c->accum;
     f.radiance = (Rgb *)c->radiance.p;
     f.counters = (unsigned long long *)c->counters.p;
@@ -364,7 +371,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
     if (no_alloc && (c->prim_dirty || c->nodes_dirty)) return fail(c, PT_E_STATE, "scene tables not on the device yet (upload the mesh and the scene first)");
     if (!no_alloc && (rc = sync_bvh(c)) != PT_OK) return rc;
     const size_t plane_bytes = (size_t)c->width * c->height * sizeof(Rgb);
-    const int n_tiles = (((c->width / 8) * 8 + kWave - 1) / kWave) * ((c->height / 8) * 8);
+    const int n_tiles = tile_count(c->width, c->height);
     if (no_alloc) {
         if (!c->scratch_dev) return fail(c, PT_E_STATE, "the static scratch array was not resolved on this device");
         if (n_tiles > kScratchMaxTiles)
@@ -895,9 +902,9 @@ int pt_read_primary_hits(pt_ctx *c, int pass, int32_t *ids, float *t, float *dir
     fp.counters = nullptr;
     fp.out_ids = d_ids; fp.out_t = d_t; fp.out_dirs = d_dirs; fp.out_rng = d_rng;
     if (pick_variant(c) >= 5)
-        hipLaunchKernelGGL(pt_primary_hits_bvh<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
+        hipLaunchKernelGGL(pt_primary_hits_bvh<kSlots>, dim3((unsigned)tile_count(c->width, c->height)), dim3(kWave), 0, c->stream, sv, fp);
     else
-        hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3((unsigned)(fp.x_blocks * fp.rows)), dim3(kWave), 0, c->stream, sv, fp);
+        hipLaunchKernelGGL(pt_primary_hits<kSlots>, dim3((unsigned)tile_count(c->width, c->height)), dim3(kWave), 0, c->stream, sv, fp);
     TRY(hipGetLastError());
     if (ids) TRY(hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (t) TRY(hipMemcpyAsync(t, d_t, n * 4, hipMemcpyDeviceToHost, c->stream));

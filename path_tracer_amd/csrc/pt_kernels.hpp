@@ -1,6 +1,6 @@
 // pt_kernels.hpp — HIP kernels of the path-tracing hot path for gfx950 (MI355X, wave64).
 //
-// Two families of trace kernels, same work decomposition (persistent waves, work items = 64 px of a row x a range of
+// Two families of trace kernels, same work decomposition (persistent waves, work items = a tile of 64 px (tile_pixel: an 8 x 8 block) x a range of
 // passes, pulled from an atomic queue in heaviest-first order), same per-sample arithmetic (pt_math.hpp):
 //
 //  * pt_trace_items_bvh_lds / pt_trace_items_bvh (default): every lane runs a small path state machine; rays that pass the
@@ -94,12 +94,12 @@ struct FrameParams {
     int max_bounces, debug_normal;
     int first_pass, n_passes; // passes of this batch: first_pass .. first_pass + n_passes - 1
     int chunk;                // passes per work item of the mesh tiles (class 0)
-    int traced_width, rows, x_blocks;   // (W/8)*8, (H/8)*8 (glDispatchCompute(W/8, H/8, 1)), ceil(traced_width/64)
+    int traced_width, rows, x_blocks;   // (W/8)*8, (H/8)*8 (glDispatchCompute(W/8, H/8, 1)), tiles per row of tiles (tile_pixel)
     int sum_mode;             // 0: running mean (rt.comp:337), 1: plain sum for the multi-GPU split
     float *accum;             // RGBA32F, row 0 = bottom
     Rgb *radiance;            // [n_passes][H][W] 1-spp radiance of this batch, 12 B per sample
     unsigned *queue;          // work-item counter, zeroed before every launch
-    // schedule (pt_tile_weights + pt_sort_tiles): tiles = 64 px of a row, sorted heaviest first, in three classes
+    // schedule (pt_tile_weights + pt_sort_tiles): tiles = 64 px (tile_pixel), sorted heaviest first, in three classes
     const unsigned *order;    // [n_tiles] tile index by rank
     const int *class_count;   // [3] tiles per class: 0 = some pixel passes the mesh gate, 1 = hits only scene primitives, 2 = sky
     int class_ppi[3];         // passes per work item for each class
@@ -115,6 +115,32 @@ struct FrameParams {
     // primary-hit probe outputs (test-only kernel)
     int32_t *out_ids; float *out_t; float *out_dirs; uint32_t *out_rng;
 };
+
+// Tile = the 64 pixels one work item covers.  PT_TILE_8X8: an 8 x 8 block (the reference's own workgroup, rt.comp:3: the
+// traced area is a whole number of them) -- the rays of a wave stay close together, so they visit the same nodes;
+// otherwise 64 pixels of one row.  x_blocks = tiles per row of tiles.  Returns false for a pixel outside the traced area.
+#ifndef PT_TILE_8X8
+#define PT_TILE_8X8 1
+#endif
+__device__ __forceinline__ bool tile_pixel(const FrameParams &fp, int tile, int r, int &x, int &y)
+{
+    const int bx = tile % fp.x_blocks, by = tile / fp.x_blocks;
+#if PT_TILE_8X8
+    x = bx * 8 + (r & 7); y = by * 8 + (r >> 3);
+    return true;
+#else
+    x = bx * kWave + r; y = by;
+    return x < fp.traced_width;
+#endif
+}
+__device__ __forceinline__ int tile_pixels(const FrameParams &fp, int tile)      // pixels of the tile inside the traced area (they come first)
+{
+#if PT_TILE_8X8
+    return kWave;
+#else
+    return min(kWave, fp.traced_width - (tile % fp.x_blocks) * kWave);
+#endif
+}
 
 template <int SLOTS>
 struct TriRegs { float p1x[SLOTS], p1y[SLOTS], p1z[SLOTS], e1x[SLOTS], e1y[SLOTS], e1z[SLOTS], e2x[SLOTS], e2y[SLOTS], e2z[SLOTS]; };
@@ -628,7 +654,7 @@ __device__ __forceinline__ void shade_hit(const SceneView &sc, const Hit &h, Pat
 // ------------------------------------------------------------------------------------------------
 // The hot kernel.  Persistent single-wave workgroups (grid = what the chip holds at 3 waves/SIMD) pull
 // work items from an atomic queue; the mesh triangles are loaded into registers once per wave for
-// the whole launch.  Work item = 64 consecutive pixels of one image row x `fp.chunk` consecutive
+// the whole launch.  Work item = one tile of 64 pixels (tile_pixel) x `fp.chunk` consecutive
 // passes.  Each lane owns one pixel and walks through its passes on its own ("persistent lane": when
 // a path ends the lane starts the primary ray of its next pass at once), so lanes stay busy although
 // path lengths differ; a sample is a pure function of (pixel, pass) (rt.comp:326-327), so this changes
@@ -663,10 +689,8 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
         const int ppi = fp.class_ppi[cls];
         const int chunk = rel % per_tile;
         const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
-        const int xb = tile % fp.x_blocks;
-        const int y = tile / fp.x_blocks;
-        const int x = xb * kWave + lane;
-        const bool valid = x < fp.traced_width;
+        int x, y;
+        const bool valid = tile_pixel(fp, tile, lane, x, y);
         const int k_end = min(fp.n_passes, (chunk + 1) * ppi);
         Rgb *rad = fp.radiance + (size_t)y * fp.width + x;
         int k = chunk * ppi;                                           // pass index relative to fp.first_pass
@@ -847,10 +871,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     const unsigned long long t_start = wall_clock64();
     unsigned *stk = st.stack;
     // Lanes are scheduled one by one: a lane that has finished its pixel takes the next unassigned pixel of the wave's
-    // current work item (64 px of a row x a range of passes), and the wave fetches another item from the queue when that
+    // current work item (a tile of 64 px x a range of passes), and the wave fetches another item from the queue when that
     // one is used up.  So a wave keeps ~64 live paths whatever their lengths, and lanes parked for the mesh can wait for
     // company without idling the others.
-    int t_valid = 0, t_next = 0, t_x0 = 0, t_y = 0, t_k0 = 0, t_kend = 0;   // wave-uniform cursor into the current item
+    int t_valid = 0, t_next = 0, t_tile = 0, t_k0 = 0, t_kend = 0;          // wave-uniform cursor into the current item
     const int static_stride = (int)(gridDim.x * (blockDim.x / kWave));
     int static_next = (int)(blockIdx.x + gridDim.x * (threadIdx.x / kWave));   // waves of one workgroup take items far apart in the list
     bool more = true;                                                       // the queue may still hold items
@@ -909,14 +933,15 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         const int ppi = fp.class_ppi[cls];
                         const int chunk = rel % per_tile;
                         const int tile = (int)fp.order[rank0 + rel / per_tile];        // wave-uniform: scalar load
-                        t_x0 = (tile % fp.x_blocks) * kWave; t_y = tile / fp.x_blocks;
+                        t_tile = tile;
                         t_k0 = chunk * ppi; t_kend = min(fp.n_passes, (chunk + 1) * ppi);
-                        t_valid = min(kWave, fp.traced_width - t_x0); t_next = 0;
+                        t_valid = tile_pixels(fp, tile); t_next = 0;
                     }
                     const int n_dead = __popcll(dead), room = t_valid - t_next;
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(dead >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dead, 0));   // dead lanes below this one
                     if (state == S_DEAD && rank < room) {
-                        x = t_x0 + t_next + rank; y = t_y; k = t_k0; k_end = t_kend;
+                        tile_pixel(fp, t_tile, t_next + rank, x, y);
+                        k = t_k0; k_end = t_kend;
                         const float W = (float)fp.width, H = (float)fp.height;
                         const float pix_off = lds_f4(st.shade, 2).x;
                         const float fx = (float)x + pix_off, fy = (float)y + pix_off;   // rt.comp:12 | rt.frag:14 (x + 0.5 is exact)
@@ -1292,10 +1317,9 @@ constexpr int kMaxTileWeight = 65 * kWave;
 __global__ void __launch_bounds__(kWave) pt_tile_weights(SceneView sc, FrameParams fp)
 {
     const int lane = threadIdx.x, tile = blockIdx.x;
-    const int xb = tile % fp.x_blocks, y = tile / fp.x_blocks;
-    const int x = xb * kWave + lane;
+    int x, y;
     bool gate = false, other = false;
-    if (x < fp.traced_width) {
+    if (tile_pixel(fp, tile, lane, x, y)) {
         const float W = (float)fp.width, H = (float)fp.height;
         const float X = -(((((float)x + sc.sh.pix_off) / W - 0.5f) * W) / H), Y = ((float)y + sc.sh.pix_off) / H - 0.5f;
         const float *m = fp.iv;
@@ -1453,9 +1477,8 @@ __global__ void __launch_bounds__(256) pt_accumulate(FrameParams fp)
 template <int SLOTS, class Store>
 __device__ __forceinline__ void primary_hits_body(const SceneView &sc, const FrameParams &fp, Store &st, int lane, int tile)
 {
-    const int xb = tile % fp.x_blocks, y = tile / fp.x_blocks;
-    const int x = xb * kWave + lane;
-    const bool valid = x < fp.traced_width;
+    int x, y;
+    const bool valid = tile_pixel(fp, tile, lane, x, y);
     v3 o = V(0, 0, 0), d = V(0, 0, 1);
     uint32_t state = 0;
     if (valid) state = primary_ray(fp, sc.sh, x, y, fp.first_pass, o, d);
