@@ -120,6 +120,7 @@ struct pt_ctx {
     std::vector<float4> h_mesh_rec, h_tri_rec;   // winner records (p1 | material, e1, e2, normal) of the mesh / the scene triangles
     bool prim_dirty = true;                      // prim_tab = h_mesh_rec ++ h_tri_rec must be rebuilt
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    float sph_bmin[3] = {0, 0, 0}, sph_bmax[3] = {0, 0, 0};   // bounds of all spheres (pt_upload_scene)
     bool have_mesh = false, have_scene = false, have_camera = false;
     uint32_t max_mat_mesh = 0, max_mat_scene = 0;   // largest material index referenced
 
@@ -245,6 +246,7 @@ SceneView scene_view(const pt_ctx *c)
     s.mats = (const PtMaterial *)c->mats.p; s.mat_fres = (const float4 *)c->mat_fres.p; s.prim_tab = (const float4 *)c->prim_tab.p;
     s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
     s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root;
+    for (int k = 0; k < 3; k++) { s.sph_bmin[k] = c->sph_bmin[k]; s.sph_bmax[k] = c->sph_bmax[k]; }
     return s;
 }
 
@@ -725,9 +727,13 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
     std::vector<float4> srec;
     {
         bool finite = true; float scale = 0.0f;
+        for (int k = 0; k < 3; k++) { c->sph_bmin[k] = INFINITY; c->sph_bmax[k] = -INFINITY; }
         for (int i = 0; i < n_sph && finite; i++) {
             const float v[4] = {sph[i].position[0], sph[i].position[1], sph[i].position[2], sph[i].radius};
             for (float x : v) { if (!std::isfinite(x)) finite = false; }
+            for (int k = 0; k < 3; k++) {
+                c->sph_bmin[k] = std::min(c->sph_bmin[k], v[k] - std::fabs(v[3])); c->sph_bmax[k] = std::max(c->sph_bmax[k], v[k] + std::fabs(v[3]));
+            }
             for (int k = 0; k < 3; k++) scale = std::max(scale, std::fabs(sph[i].position[k]) + std::fabs(sph[i].radius));
         }
         if (n_sph > 0 && finite && scale < 1e18f) {

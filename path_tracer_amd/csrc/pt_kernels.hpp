@@ -81,6 +81,7 @@ struct SceneView {
     const float4 *bvh_tris;   // 3 x float4 per triangle in leaf order: (p1, bits(original index)), e1, e2
     float bvh_scale;          // largest |coordinate| of the mesh and the spheres (for the traversal's safety margin)
     const float4 *bvh_sph;    // sphere tree leaves, 2 x float4 per sphere in leaf order: (centre, radius), (bits(sphere index), -, -, -)
+    float sph_bmin[3], sph_bmax[3];   // bounds of all spheres (centre -+ |radius|); read once per workgroup (stage_scene_lds)
     int sph_root;             // node index of the sphere tree's root in bvh_nodes, -1: spheres are scanned one by one
 };
 
@@ -777,8 +778,8 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 // In front of them, always: the shading parameters that are read once per path or per pixel (sky, jitter scale, origin
 // offset, pixel-centre offset) -- as kernel arguments they would sit in SGPRs through the traversal loops, where the
 // kernel already spills; here they cost one ds_read at the point of use.  (sky | jitter_scale), (sky_emit | origin_offset),
-// (pix_off, -, -, -).
-constexpr int kShadeLdsVecs = 3;
+// (pix_off, -, -, -), then the box of all spheres (min, max).
+constexpr int kShadeLdsVecs = 5;
 constexpr int kSceneLdsTris = 16;                                  // scenes with more triangles keep the scalar path
 constexpr int kSceneLdsVecs = kShadeLdsVecs + 3 * kSceneLdsTris + 5;
 __device__ __forceinline__ bool stage_scene_lds(float4 *dst, const SceneView &sc, const FrameParams &fp, int tid, int n_threads)
@@ -787,6 +788,8 @@ __device__ __forceinline__ bool stage_scene_lds(float4 *dst, const SceneView &sc
         dst[0] = make_float4(sc.sh.sky[0], sc.sh.sky[1], sc.sh.sky[2], sc.sh.jitter_scale);
         dst[1] = make_float4(sc.sh.sky_emit[0], sc.sh.sky_emit[1], sc.sh.sky_emit[2], sc.sh.origin_offset);
         dst[2] = make_float4(sc.sh.pix_off, 0.0f, 0.0f, 0.0f);
+        dst[3] = make_float4(sc.sph_bmin[0], sc.sph_bmin[1], sc.sph_bmin[2], 0.0f);      // the box of all spheres (sphere tree's root)
+        dst[4] = make_float4(sc.sph_bmax[0], sc.sph_bmax[1], sc.sph_bmax[2], 0.0f);
     }
     dst += kShadeLdsVecs;
     if (sc.n_tris > kSceneLdsTris) return false;
@@ -1237,15 +1240,30 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 n_mesh_seg += __popcll(wave_ballot(gate));
                 n_prim_mesh_seg += __popcll(wave_ballot(gate) & wave_ballot(ps.bounces == 0));
                 if (state == S_TRACE) {
-                    if (gate || sph_root >= 0) {
-                        // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree always
+                    // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree whenever the ray can
+                    // meet the box of all spheres -- the traversal's own conservative slab test, one node visit's worth, here
+                    // where it saves the ray a whole turn of parking
+                    bool sph_in = false;
+                    if (SPH && sph_root >= 0) {
+                        inv = V(slab_inv(ps.d.x), slab_inv(ps.d.y), slab_inv(ps.d.z));
+                        delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
+                        const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
+                        const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
+                        const float4 bn = lds_f4(st.shade, 3), bx = lds_f4(st.shade, 4);
+                        float b0, b1;
+                        slab_test_fma(bn.x, bn.y, bn.z, bx.x, bx.y, bx.z, nlo, nhi, inv, b0, b1);
+                        sph_in = b0 <= b1 && b1 >= sc.sh.box_slack;
+                    }
+                    if (gate || sph_in) {
                         state = S_MESH;
                         sp = 1; best_t = kInfinity; best_id = -1;
                         cur = gate ? 0 : sph_root;
-                        if (gate && sph_root >= 0) { stk[kWave] = (unsigned)sph_root; sp = 2; }
+                        if (gate && sph_in) { stk[kWave] = (unsigned)sph_root; sp = 2; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
-                        inv = V(slab_inv(ps.d.x), slab_inv(ps.d.y), slab_inv(ps.d.z));
-                        delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
+                        if (!(SPH && sph_root >= 0)) {
+                            inv = V(slab_inv(ps.d.x), slab_inv(ps.d.y), slab_inv(ps.d.z));
+                            delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
+                        }
                     } else {
                         state = S_READY;
                         best_t = s_t; best_id = s_id;
