@@ -1057,13 +1057,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     }
                     const bool fin = new_cur == kTravDone && cur != kTravDone;      // popped the bottom of the stack
                     cur = new_cur;
-                    if (wave_any(fin)) {
-                        // merge with the primitives scanned one by one: the reference's in-order strict `<` scan returns
-                        // the lexicographic minimum of (t, canonical id)
-                        const bool take = fin & (s_id >= 0) & closer_hit(s_t, s_id, best_t, best_id);
-                        best_t = take ? s_t : best_t; best_id = take ? s_id : best_id;
-                        state = fin ? S_READY : state;
-                    }
+                    state = fin ? S_READY : state;
                 }
             } else if (n_mesh) {
                 wait++;
@@ -1256,7 +1250,10 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     }
                     if (gate || sph_in) {
                         state = S_MESH;
-                        sp = 1; best_t = kInfinity; best_id = -1;
+                        // the traversal starts from the hit among the primitives scanned one by one: the reference's in-order
+                        // strict `<` scan returns the lexicographic minimum of (t, canonical id) over all of them, so the order
+                        // of the candidates is free -- and subtrees beyond that hit are pruned from the first step
+                        sp = 1; best_t = s_t; best_id = s_id;
                         cur = gate ? 0 : sph_root;
                         if (gate && sph_in) { stk[kWave] = (unsigned)sph_root; sp = 2; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
