@@ -231,6 +231,9 @@ def main():
     # rehearsal on a one-GPU box (not a measurement): PT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and swaps RCCL,
     # which refuses two ranks on one device, for gloo -- the rest of the N > 1 path is the real one
     rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    # how the rehearsal orders the ranks on the shared device (diagnostic switches; both on by default)
+    reh_turns = os.environ.get("PT_REHEARSAL_TURNS", "1") == "1"
+    reh_host = os.environ.get("PT_REHEARSAL_HOST_REDUCE", "1") == "1"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -272,9 +275,26 @@ def main():
             return
         # rank g traces passes g*SPP+1 .. (g+1)*SPP as a sum; ONE reduce onto rank 0 (RCCL over xGMI); rank 0 scales
         first, count = D.pass_range(rank, world, SPP * world, 1)
-        accum.zero_()
-        if count:
-            r.render_sum(first, count)
+        if rehearsal and reh_turns:
+            # one GPU, several processes: the ranks take the device in turn, so that no two processes ever have a kernel
+            # in flight at once (what stalled was the device time-slicing two processes' persistent grids)
+            for turn in range(world):
+                if turn == rank:
+                    accum.zero_()
+                    if count:
+                        r.render_sum(first, count)
+                    stream.synchronize()
+                dist.barrier()
+        else:
+            accum.zero_()
+            if count:
+                r.render_sum(first, count)
+        if rehearsal:
+            D.reduce_and_finish(accum, SPP * world, 0, None, r, check, stage_on_host=reh_host)
+            if reh_turns:
+                stream.synchronize()
+                dist.barrier()
+            return
         if time_reduce and not rehearsal:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
@@ -302,7 +322,7 @@ def main():
         durs.append(r.last_render_ms())
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")     # gloo reduces host memory
     if split:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -109,6 +109,23 @@ def main():
             json.dump({"source": "reference GLM 0.9.8.5 via oracle/glm_camera_ref.cpp (call sequence of src/Camera.cpp:13-26)",
                        "cameras": cams}, fh, indent=1)
         print("camera:", len(cams))
+    # ---- the reference's own Camera (src/Camera.cpp, compiled where it lies) driven through key scripts -------------
+    if want("camera_input"):
+        scripts = [((1.5, 0.4, 0.0, 0.0, 0.0), ["W:0.5", "A:0.25", "-:0.1", "WD:0.016", "EQ:0.3", "Q:0.3", "S:1"]),
+                   ((1.2, 0.9, 0.8, 33.0, 24.0), ["WE:0.37", "SA:0.11", "QD:0.29", "W:0.016", "WS:0.2", "AD:0.2", "-:0.5", "D:0.0069444445"]),
+                   ((-2.0, 1.1, 0.7, 170.0, -35.0), ["S:0.125", "S:0.125", "E:0.01", "WASDEQ:0.05", "-:0", "A:3.5"])]
+        res = []
+        for start, steps in scripts:
+            out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "camera_input_ref"), *[f"{v:.9g}" for v in start], *steps],
+                                 check=True, capture_output=True, text=True).stdout.strip().splitlines()
+            assert len(out) == len(steps)
+            res.append({"start": list(start), "steps": steps, "frames": [ln.split() for ln in out]})
+        with open(os.path.join(GOLD, "camera_input.json"), "w") as fh:
+            json.dump({"source": "the reference's src/Camera.cpp (ProcessInput + UpdateView in the order of src/Main.cpp:110-120) compiled "
+                                 "where it lies with its vendored GLM, glfwGetKey supplied by oracle/camera_input_ref.cpp",
+                       "frame_words": "position(3) forward(3) right(3) up(3) inverseView(16, column-major) as hex float32, then `moving`",
+                       "scripts": res}, fh, indent=1)
+        print("camera_input:", len(res))
     bench_cam, mixed_cam, rot_cam = cam_from_bits(cams[1]), cam_from_bits(cams[2]), cam_from_bits(cams[3])
 
     dsc, msc = S.default_scene(), S.mixed_scene()

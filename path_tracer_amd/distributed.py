@@ -24,17 +24,30 @@ def pass_range(rank: int, world: int, total_spp: int, first_pass: int = 1):
     return first, count
 
 
-def reduce_and_finish(accum, total_spp: int, dst: int = 0, group=None, renderer=None, check: bool = True):
+def reduce_and_finish(accum, total_spp: int, dst: int = 0, group=None, renderer=None, check: bool = True, stage_on_host: bool = False):
     """Sum the per-rank sum buffers onto `dst` (one collective) and turn the sum into the mean there.
     `accum`: (H, W, 4) float32 tensor holding this rank's sum (alpha = number of passes it traced).
     `renderer`: if it offers `scale_accum` (capi.Renderer), the finish is ONE library kernel (pt_scale_accum) on the
     renderer's stream -- which must be the stream torch issues the reduce on (bench.py sets both); otherwise torch ops.
     `check`: read the summed sample count back and compare it with total_spp (a host synchronisation: callers in a
-    timed loop switch it off after their warm-up).  Returns True on the rank that now holds the finished image."""
+    timed loop switch it off after their warm-up).
+    `stage_on_host`: for a host-side backend (gloo) with a device tensor -- the one-GPU rehearsal of bench.py: the caller's
+    stream is drained, the image crosses to the host with one plain blocking copy, the backend reduces host memory, and the
+    root copies the sum back.  gloo's own path for device tensors does the same staging on streams of its own (a
+    high-priority pool stream per call, a pinned cache, a worker thread that synchronises that stream); keeping it out
+    leaves exactly one stream per process on the device.  Returns True on the rank that now holds the finished image."""
     import torch.distributed as dist
 
     if dist.is_initialized():
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)      # a group of one still goes through the backend
+        if stage_on_host and accum.is_cuda:
+            import torch
+            torch.cuda.current_stream(accum.device).synchronize()
+            host = accum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if dist.get_rank(group) == dst:
+                accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)      # a group of one still goes through the backend
         is_root = dist.get_rank(group) == dst
     else:
         is_root = True

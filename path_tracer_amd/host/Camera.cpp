@@ -17,21 +17,23 @@ void Camera::UpdateView()
 // along -forward exactly as the reference does.
 void Camera::ProcessInput(unsigned keys, float dt)
 {
-    const float step = speed * dt;
-    if (keys & KEY_W) { moving = true; position -= forward * step; }
-    else if (keys & KEY_S) { moving = true; position += forward * step; }
-    if (keys & KEY_A) { moving = true; position -= right * step; }
-    else if (keys & KEY_D) { moving = true; position += right * step; }
-    if (keys & KEY_E) { moving = true; position += up * step; }
-    else if (keys & KEY_Q) { moving = true; position -= up * step; }
+    // `position -= forward * speed * dt` (src/Camera.cpp:33): (forward * speed) * dt, two roundings per component
+    if (keys & KEY_W) { moving = true; position -= forward * speed * dt; }
+    else if (keys & KEY_S) { moving = true; position += forward * speed * dt; }
+    if (keys & KEY_A) { moving = true; position -= right * speed * dt; }
+    else if (keys & KEY_D) { moving = true; position += right * speed * dt; }
+    if (keys & KEY_E) { moving = true; position += up * speed * dt; }
+    else if (keys & KEY_Q) { moving = true; position -= up * speed * dt; }
 }
 
 void Camera::MouseLook(float xOffset, float yOffset)
 {
     if (std::fabs(xOffset) > 0 || std::fabs(yOffset) > 0) moving = true;
     const float sensitivity = 0.1f;
-    yaw += xOffset * sensitivity;
-    pitch -= yOffset * sensitivity;
+    xOffset *= sensitivity;
+    yOffset *= sensitivity;
+    yaw += xOffset;
+    pitch -= yOffset;
     if (pitch > 89.0f) pitch = 89.0f;
     if (pitch < -89.0f) pitch = -89.0f;
     forward = normalize(vec3(std::cos(radians(yaw)) * std::cos(radians(pitch)), std::sin(radians(pitch)),

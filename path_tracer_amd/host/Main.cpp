@@ -6,6 +6,15 @@
 //           [--orbit FRAMES DEGREES]   scripted stand-in for the interactive loop (src/Main.cpp:108-150): every frame the
 //                                      camera turns by DEGREES of yaw around the scene centre, which restarts the
 //                                      accumulation (currAccumPass = 0 + clear, src/Main.cpp:110-117), then --spp passes
+//           [--keys SCRIPT]            the interactive loop itself (src/Main.cpp:108-150) with scripted input, one frame per
+//                                      comma-separated step: KEYS:DT (KEYS = letters out of WASDEQN or '-', DT = the frame's
+//                                      deltaTime in seconds) or @X:Y (a mouse move to X,Y delivered before the next frame,
+//                                      Renderer::MouseCallback).  Per frame, in the reference's order: a camera that moved in
+//                                      the previous frame restarts the count (currAccumPass = 0; the image itself is NOT
+//                                      cleared: pass 1 blends with weight 1/1, rt.comp:337), ProcessInput, UpdateView, N toggles
+//                                      debugNormal on the key's edge, currAccumPass++, dispatch.  --spp is ignored.
+//           [--print-input SCRIPT]     host-only: the same loop without rendering; prints per frame position, forward, right,
+//                                      up, inverseView as hex float32 words and `moving` (tests against the reference's Camera)
 //           [--add-mesh PATH MATERIAL]  (repeatable) further OBJ files, merged with --mesh into one traced mesh
 //           [--group RANK WORLD IDFILE] one process per GPU (give each its --device): the --spp passes are split over the
 //                                      WORLD ranks, one RCCL reduce brings the sums to rank 0, which writes the outputs
@@ -14,6 +23,7 @@
 //                                      RGBA32F image, row 0 = bottom row, as --out writes it
 //           [--handshake-only RANK WORLD IDFILE]  host-only: run just the id-file protocol of --group (GroupHandshake.h) with
 //                                      a stand-in id made on rank 0 and print the id every rank ends up with (tests)
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -51,6 +61,48 @@ static void default_materials(Scene &scene)
     scene.materials.push_back(sun);
 }
 
+// One frame of scripted input (--keys / --print-input): a key set held during the frame with the frame's deltaTime, or a
+// mouse move delivered by glfwPollEvents before it.
+struct InputStep { bool mouse = false; unsigned keys = 0; bool n_key = false; float dt = 0.0f; double mx = 0.0, my = 0.0; };
+
+static bool parse_input_script(const std::string &script, std::vector<InputStep> &out)
+{
+    size_t pos = 0;
+    while (pos <= script.size()) {
+        const size_t comma = std::min(script.find(',', pos), script.size());
+        const std::string tok = script.substr(pos, comma - pos);
+        pos = comma + 1;
+        if (tok.empty()) { if (comma >= script.size()) break; continue; }
+        InputStep st;
+        const size_t colon = tok.find(':');
+        if (colon == std::string::npos) return false;
+        if (tok[0] == '@') {
+            st.mouse = true;
+            st.mx = std::strtod(tok.c_str() + 1, nullptr); st.my = std::strtod(tok.c_str() + colon + 1, nullptr);
+        } else {
+            for (size_t k = 0; k < colon; k++)
+                switch (tok[k]) {
+                case 'W': st.keys |= KEY_W; break; case 'S': st.keys |= KEY_S; break; case 'A': st.keys |= KEY_A; break;
+                case 'D': st.keys |= KEY_D; break; case 'E': st.keys |= KEY_E; break; case 'Q': st.keys |= KEY_Q; break;
+                case 'N': st.n_key = true; break; case '-': break;
+                default: return false;
+                }
+            st.dt = std::strtof(tok.c_str() + colon + 1, nullptr);
+        }
+        out.push_back(st);
+        if (comma >= script.size()) break;
+    }
+    return !out.empty();
+}
+
+static void print_camera_state(const Camera &c)
+{
+    auto put = [](float f) { unsigned u; std::memcpy(&u, &f, 4); std::printf("%08x ", u); };
+    for (const vec3 &v : {c.position, c.forward, c.right, c.up}) { put(v.x); put(v.y); put(v.z); }
+    for (int k = 0; k < 16; k++) put(c.inverseView.data()[k]);
+    std::printf("%d\n", c.moving ? 1 : 0);
+}
+
 int main(int argc, char **argv)
 {
     std::string mesh_path = "res/meshes/bunny1.obj", scene_name = "default", out_path, ppm_path, shader_path = "res/shaders/rt.comp";
@@ -58,6 +110,7 @@ int main(int argc, char **argv)
     bool debugNormal = false, batch = false, cam_given = false, print_camera = false;
     float cam[5] = {1.5f, 0.4f, 0.0f, 0.0f, 0.0f};
     int orbit_frames = 0; float orbit_deg = 0.0f;
+    std::string keys_script; bool print_input = false;
     std::vector<std::pair<std::string, int>> more_meshes;               // --add-mesh PATH MATERIAL (repeatable)
     int group_rank = 0, group_world = 0; std::string group_id_path;     // --group: one process per GPU, samples split over RCCL
     bool handshake_only = false; double handshake_timeout = 60.0;
@@ -77,6 +130,8 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--batch")) batch = true;
         else if (!std::strcmp(argv[i], "--print-camera")) print_camera = true;
         else if (!std::strcmp(argv[i], "--orbit")) { orbit_frames = std::atoi(next()); orbit_deg = std::strtof(next(), nullptr); }
+        else if (!std::strcmp(argv[i], "--keys")) keys_script = next();
+        else if (!std::strcmp(argv[i], "--print-input")) { keys_script = next(); print_input = true; }
         else if (!std::strcmp(argv[i], "--add-mesh")) { const char *p = next(); more_meshes.emplace_back(p, std::atoi(next())); }
         else if (!std::strcmp(argv[i], "--group")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); }
         else if (!std::strcmp(argv[i], "--handshake-only")) { group_rank = std::atoi(next()); group_world = std::atoi(next()); group_id_path = next(); handshake_only = true; }
@@ -98,6 +153,21 @@ int main(int argc, char **argv)
         c.yaw = cam[3]; c.pitch = cam[4];
         c.UpdateView();
         for (int k = 0; k < 16; k++) { unsigned u; std::memcpy(&u, c.inverseView.data() + k, 4); std::printf("%08x%c", u, k == 15 ? '\n' : ' '); }
+        return 0;
+    }
+    std::vector<InputStep> input;
+    if (!keys_script.empty() && !parse_input_script(keys_script, input)) { std::fprintf(stderr, "bad input script '%s'\n", keys_script.c_str()); return 2; }
+    if (print_input) {      // host-only: Camera::ProcessInput / MouseLook / UpdateView in the frame loop's order, no rendering
+        Camera &c = Renderer::camera;
+        c.position = vec3(cam[0], cam[1], cam[2]); c.yaw = cam[3]; c.pitch = cam[4];
+        c.UpdateView();
+        for (const InputStep &st : input) {
+            if (st.mouse) { Renderer::MouseCallback(st.mx, st.my); std::printf("mouse %.9g %.9g %d\n", c.yaw, c.pitch, c.moving ? 1 : 0); continue; }
+            if (c.moving) c.moving = false;
+            c.ProcessInput(st.keys, st.dt);
+            c.UpdateView();
+            print_camera_state(c);
+        }
         return 0;
     }
     if (group_world > 0 && (group_rank < 0 || group_rank >= group_world)) { std::fprintf(stderr, "bad rank %d of %d\n", group_rank, group_world); return 2; }
@@ -175,6 +245,33 @@ int main(int argc, char **argv)
         std::printf("Frames: %d x %d spp | %.3f ms per frame | %.1f frames/s | final camera %.9g %.9g %.9g yaw %.9g\n", orbit_frames, spp,
                     dt * 1e3 / orbit_frames, orbit_frames / dt, Renderer::camera.position.x, Renderer::camera.position.y,
                     Renderer::camera.position.z, Renderer::camera.yaw);
+    } else if (!input.empty()) {
+        // src/Main.cpp:108-150 with scripted input.  Kept from the reference on purpose: the frame in which a key goes down
+        // still blends into the old image (the count restarts one frame later), and a restart does not clear the image --
+        // pass 1 is accum + 1.0 * (colour - accum) (rt.comp:337), which the short-launch kernels evaluate as written.
+        int currAccumPass = 0, frames = 0;
+        bool keyPressed = false;
+        for (const InputStep &st : input) {
+            if (st.mouse) { Renderer::MouseCallback(st.mx, st.my); continue; }      // glfwPollEvents at the end of the previous frame
+            if (Renderer::camera.moving) { currAccumPass = 0; Renderer::camera.moving = false; }
+            Renderer::camera.ProcessInput(st.keys, st.dt);
+            Renderer::camera.UpdateView();
+            if (st.n_key) {
+                if (!keyPressed) { debugNormal = !debugNormal; computeProgram.SetUniform1i("debugNormal", debugNormal); }
+                keyPressed = true;
+            } else {
+                keyPressed = false;
+            }
+            currAccumPass++;
+            computeProgram.SetUniform1i("currAccumPass", currAccumPass);
+            computeProgram.SetUniformCamera(Renderer::camera);
+            computeProgram.Dispatch();
+            frames++;
+        }
+        if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
+        std::printf("Input frames: %d | Samples: %d | final camera %.9g %.9g %.9g yaw %.9g pitch %.9g | debugNormal %d\n", frames, currAccumPass,
+                    Renderer::camera.position.x, Renderer::camera.position.y, Renderer::camera.position.z, Renderer::camera.yaw,
+                    Renderer::camera.pitch, debugNormal ? 1 : 0);
     } else if (group_world > 0) {
         // rank 0 makes the RCCL id; it travels through IDFILE (GroupHandshake.h: nonce-checked, so a file left by a run that
         // died is never taken for this run's)
@@ -199,7 +296,7 @@ int main(int argc, char **argv)
         }
     }
     if (!Renderer::Check(pt_synchronize(Renderer::ctx), "pt_synchronize")) return 1;
-    if (orbit_frames <= 0) {
+    if (orbit_frames <= 0 && input.empty()) {
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("Samples: %d | %.3f ms | %.1f Msamples/s\n", spp, dt * 1e3, (double)width * height * spp / dt * 1e-6);
     }

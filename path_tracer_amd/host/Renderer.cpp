@@ -39,7 +39,8 @@ void Shutdown()
 
 void MouseCallback(double xpos, double ypos)
 {
-    const float xOffset = (float)xpos - camera.mouseLastX, yOffset = camera.mouseLastY - (float)ypos;
+    // src/Renderer.cpp:144-145: the differences are taken in double (xpos, ypos are doubles) and narrowed afterwards
+    const float xOffset = (float)(xpos - (double)camera.mouseLastX), yOffset = (float)((double)camera.mouseLastY - ypos);
     camera.mouseLastX = (float)xpos;
     camera.mouseLastY = (float)ypos;
     camera.MouseLook(xOffset, yOffset);

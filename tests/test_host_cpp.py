@@ -253,3 +253,83 @@ def test_present_values_follow_the_srgb_transfer_and_gl_row_order(tmp_path):
     assert np.all(first == 188)
     # anchors of the transfer function itself
     assert _srgb8_expected(np.array([0.0, 1.0, 0.0031308, 0.2158605, 0.5]))[0].tolist() == [0, 255, 10, 128, 188]
+
+
+# ---- the input path of the interactive loop (src/Camera.cpp:28-59, src/Renderer.cpp:142-166, src/Main.cpp:108-150) ----------
+
+def _print_input(start, script):
+    out = subprocess.run([PT_MAIN, "--print-input", script, "--cam", *[f"{v:.9g}" for v in start]], check=True, capture_output=True, text=True)
+    return [ln.split() for ln in out.stdout.strip().splitlines()]
+
+
+def test_process_input_matches_the_reference_camera():
+    """Camera::ProcessInput + UpdateView (host/Camera.cpp) against the reference's own src/Camera.cpp, compiled where it lies
+    (oracle/camera_input_ref.cpp -> tests/golden/camera_input.json): every key, key pairs (W wins over S, A over D, E over Q),
+    no key, dt = 0; position / forward / right / up / inverseView bit for bit and the `moving` flag after each frame"""
+    d = json.load(open(os.path.join(GOLD, "camera_input.json")))
+    assert len(d["scripts"]) >= 3
+    for sc in d["scripts"]:
+        got = _print_input(sc["start"], ",".join(sc["steps"]))
+        assert got == sc["frames"], sc["steps"]
+    # W moves along -forward (src/Camera.cpp:30-34), E up, Q down; a frame without keys leaves `moving` cleared
+    f = lambda w: np.array([int(x, 16) for x in w], np.uint32).view(np.float32)
+    fr = d["scripts"][0]["frames"]
+    assert d["scripts"][0]["steps"][0] == "W:0.5" and f(fr[0][:3])[0] == np.float32(1.5) - np.float32(2.0) * np.float32(0.5)
+    assert fr[0][-1] == "1" and fr[2][-1] == "0"
+
+
+def test_mouse_look_follows_renderer_mouse_callback():
+    """Renderer::MouseCallback / Camera::MouseLook against a float32 restatement of src/Renderer.cpp:142-166: offsets taken in
+    double and narrowed, sensitivity 0.1, yaw += x, pitch -= (lastY - y), clamp to +-89 degrees, `moving` set by any motion"""
+    f32 = np.float32
+    moves = [(10.0, 5.0), (10.0, 5.0), (13.25, -40.5), (2000.0, -3000.0), (1999.5, 9000.0), (1999.5, 8999.0)]
+    script = ",".join("@%.9g:%.9g" % m for m in moves)
+    got = _print_input((0.3, 0.2, 0.1, 12.5, -3.0), script)
+    yaw, pitch, lx, ly = f32(12.5), f32(-3.0), f32(0.0), f32(0.0)
+    for (x, y), line in zip(moves, got):
+        xo, yo = f32(x - float(lx)), f32(float(ly) - y)              # :144-145
+        lx, ly = f32(x), f32(y)
+        moving = abs(xo) > 0 or abs(yo) > 0                          # :149
+        xo, yo = f32(xo * f32(0.1)), f32(yo * f32(0.1))              # :151-153
+        yaw, pitch = f32(yaw + xo), f32(pitch - yo)                  # :155-156
+        pitch = min(max(pitch, f32(-89.0)), f32(89.0))               # :158-159
+        assert line[0] == "mouse" and f32(line[1]) == yaw and f32(line[2]) == pitch, (x, y, line)
+        # `moving` stays set until the frame loop clears it; the second event repeats the position: no motion on its own
+        assert line[3] == "1" or not moving
+    # the cursor going UP the screen (smaller y) gives a positive yOffset, and `pitch -= yOffset` (:156) turns the camera DOWN
+    assert f32(got[3][2]) == f32(-89.0) and f32(got[4][2]) == f32(89.0)
+    # a mouse move alone restarts the count: the next frame sees moving = 1 and clears it
+    got = _print_input((0, 0, 0, 0, 0), "@1:0,-:0.016,-:0.016")
+    assert got[0][3] == "1" and got[1][-1] == "0" and got[2][-1] == "0"
+
+
+@pytest.mark.gpu
+def test_pt_main_keys_loop_keeps_the_reference_frame_order(tmp_path):
+    """`pt_main --keys`: src/Main.cpp:108-150 with scripted input.  Emulated frame by frame with the oracle: the frame in which
+    W goes down still blends into the old image as pass 3, the count restarts one frame later WITHOUT clearing the image
+    (pass 1 = accum + 1.0 * (colour - accum), rt.comp:337), N toggles debugNormal on the key's edge only"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    from path_tracer_amd import scene as S
+    W, H, B = 64, 40, 4
+    script = "-:0.016,-:0.016,W:0.05,-:0.016,-:0.016,N:0.016,N:0.016,-:0.016,@3:-2,-:0.016"
+    obj, out = tmp_path / "bunny1.obj", tmp_path / "keys.f32"
+    _write_obj(obj)
+    r = subprocess.run([PT_MAIN, "--mesh", str(obj), "--width", str(W), "--height", str(H), "--bounces", str(B), "--keys", script,
+                        "--out", str(out)], check=True, capture_output=True, text=True, timeout=120)
+    assert "Input frames: 9 | Samples: 1 " in r.stdout and "debugNormal 1" in r.stdout, r.stdout
+    got = np.fromfile(out, np.float32).reshape(H, W, 4)
+    frames = _print_input((1.5, 0.4, 0.0, 0.0, 0.0), script)
+    sc = S.default_scene()
+    img = np.zeros((H, W, 4), np.float32)
+    passes = [1, 2, 3, 1, 2, 3, 4, 5, 1]                 # W in frame 3 -> restart in frame 4; the mouse move -> restart in the last frame
+    debug = [0, 0, 0, 0, 0, 1, 1, 1, 1]
+    cams = [ln for ln in frames if ln[0] != "mouse"]
+    assert len(cams) == len(passes)
+    for ln, p, dbg in zip(cams, passes, debug):
+        w = np.array([int(x, 16) for x in ln[:-1]], np.uint32).view(np.float32)
+        cam = S.Camera(position=w[:3].copy())
+        cam.inverseView = w[12:28].reshape(4, 4).copy()
+        O.Oracle(sc, cam, W, H, B, debug_normal=bool(dbg)).render(p, 1, accum=img)
+    assert np.array_equal(got.view(np.uint32), img.view(np.uint32))
