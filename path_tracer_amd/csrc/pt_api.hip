@@ -48,6 +48,11 @@ thread_local std::string g_create_error;
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned char *g_scratch_ptr[kMaxDevices] = {nullptr};
+// One event per device, recorded after the last launch of every pt_render_static call and waited for by the next one
+// before it touches the array: contexts launch on streams of their own, and without it a second context's schedule
+// kernels would overwrite what the first context's trace kernel is still reading.  Created with the array's address, at
+// pt_create time, so that the render path itself creates nothing.
+hipEvent_t g_scratch_event[kMaxDevices] = {nullptr};
 
 // device address of `scratch` on `device` (which must be the current device); resolved once per device
 hipError_t scratch_base(int device, unsigned char **out)
@@ -56,9 +61,10 @@ hipError_t scratch_base(int device, unsigned char **out)
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
         unsigned char *p = nullptr;
-        const hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
+        hipError_t e = hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!p) return hipErrorInvalidSymbol;
+        if (!g_scratch_event[device] && (e = hipEventCreateWithFlags(&g_scratch_event[device], hipEventDisableTiming)) != hipSuccess) return e;
         g_scratch_ptr[device] = p;
     }
     *out = g_scratch_ptr[device];
@@ -78,6 +84,14 @@ struct DevBuf {
         }
         if (n) return hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, s);
         return hipSuccess;
+    }
+    hipError_t ensure(size_t n)          // at least n bytes, contents undefined
+    {
+        if (p && n <= bytes) return hipSuccess;
+        if (p) { hipError_t e0 = hipFree(p); if (e0 != hipSuccess) return e0; p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e == hipSuccess) bytes = n ? n : 16;
+        return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
@@ -133,6 +147,10 @@ struct pt_ctx {
     PtShadingParams shading;          // pt_set_shading_params; pt_create fills in preset 0 (rt.comp)
     std::vector<float> h_ior;         // material.ior of the uploaded materials (the Fresnel table depends on shading.fresnel_n1_one)
     // scheduling options (pt_set_option; 0 = the built-in choice for the launch at hand)
+    // pt_set_option("verify", n): every n-th render of the traversal kernels is repeated by the brute-force kernel and compared
+    int opt_verify = 0, opt_verify_inject = 0;
+    unsigned verify_calls = 0, verify_runs = 0;
+    DevBuf verify_before, verify_exact, verify_diff;
     int opt_park_high = 0, opt_park_wait = 0, opt_refill_min = 0, opt_park_exit = 0, opt_ppi1_mul = 4, opt_ppi2_mul = 8, opt_no_fused = 0, opt_wgs_per_cu = 0, opt_lds_block = 0;
 };
 
@@ -302,6 +320,28 @@ size_t bvh_lds_bytes(const pt_ctx *c, int block)
     return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
            + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * (size_t)block;
 }
+// The LDS-resident traversal kernels take more dynamic LDS than a kernel may by default: the cap is lifted for every
+// instantiation once per device, at pt_create, so that no render call -- pt_render_static under graph capture in particular --
+// has to touch function attributes.  The attribute only permits; what a launch takes is its own argument.
+std::mutex g_attr_mutex;
+bool g_attr_done[kMaxDevices] = {false};
+hipError_t allow_large_lds(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    if (g_attr_done[device]) return hipSuccess;
+    for (int wide = 0; wide < 2; wide++)
+        for (int sph = 0; sph < 2; sph++)
+            for (int fused = 0; fused < 2; fused++)
+                for (int gen = 0; gen < 2; gen++) {
+                    const hipError_t e = hipFuncSetAttribute(kBvhLdsKernels[wide][sph][fused][gen].fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             (int)(wide ? kBvhLdsLimitWide : kBvhLdsLimit));
+                    if (e != hipSuccess) return e;
+                }
+    g_attr_done[device] = true;
+    return hipSuccess;
+}
+
 // 512 when the trees fit twice per CU, else 1024 (one shared copy per CU), 0: not at all (variant 5 reads them from global memory)
 int bvh_lds_block(const pt_ctx *c)
 {
@@ -340,6 +380,16 @@ int sync_bvh(pt_ctx *c)
                 all.push_back(nd);
             }
         }
+        if (c->opt_verify_inject && mesh && !all.empty()) {
+            // test hook for the "verify" option: a deliberately WRONG tree -- the root's child boxes shrunk to half their
+            // size -- so that the traversal skips triangles it must not skip
+            BvhNode &r0 = all[0];
+            for (int k = 0; k < 3; k++) {
+                const float lc = 0.5f * (r0.lmin[k] + r0.lmax[k]), lh = 0.25f * (r0.lmax[k] - r0.lmin[k]);
+                const float rc = 0.5f * (r0.rmin[k] + r0.rmax[k]), rh = 0.25f * (r0.rmax[k] - r0.rmin[k]);
+                r0.lmin[k] = lc - lh; r0.lmax[k] = lc + lh; r0.rmin[k] = rc - rh; r0.rmax[k] = rc + rh;
+            }
+        }
         HIPCHK(c, c->bvh_nodes.upload(all.data(), all.size() * sizeof(BvhNode), c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->bvh_n_nodes = (int)all.size();
@@ -364,7 +414,31 @@ int pick_variant(const pt_ctx *c)
 
 // no_alloc (pt_render_static): queue, schedule and workspace live in the static scratch array; nothing is allocated, created or
 // freed on the way (no hipMalloc / hipFree / hipEventCreate), and sizes the array cannot hold are refused.
+int launch_trace_impl(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_alloc);
+
 int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_alloc = false)
+{
+    if (!no_alloc) return launch_trace_impl(c, first_pass, n_passes, sum_mode, false);
+    // pt_render_static: every context on this GPU uses the same array.  The whole call is enqueued under the lock, behind
+    // the event the previous call (of whatever context) recorded after its last launch, and records that event again at its
+    // end -- two stream operations, nothing allocated.  Under stream capture the event calls are left out (an event
+    // recorded outside the capture cannot be waited for inside it): a captured call is ordered by the graph's own edges, and
+    // the caller must not run two such graphs, or a graph and a direct call, on one GPU at the same time.
+    if (!c) return PT_E_INVALID;
+    Bind b(c); HIPCHK(c, b.e);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    HIPCHK(c, hipStreamIsCapturing(c->stream, &cap));
+    hipEvent_t ev = (c->device >= 0 && c->device < kMaxDevices) ? g_scratch_event[c->device] : nullptr;
+    const bool ordered = cap == hipStreamCaptureStatusNone && ev != nullptr;
+    if (ordered) HIPCHK(c, hipStreamWaitEvent(c->stream, ev, 0));
+    const int rc = launch_trace_impl(c, first_pass, n_passes, sum_mode, true);
+    // recorded even after a failure part-way: whatever was enqueued before it still reads the array
+    if (ordered) { const hipError_t e = hipEventRecord(ev, c->stream); if (rc == PT_OK && e != hipSuccess) return fail(c, PT_E_HIP, "hipEventRecord: %s", hipGetErrorString(e)); }
+    return rc;
+}
+
+int launch_trace_impl(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_alloc)
 {
     int rc = check_ready(c);
     if (rc) return rc;
@@ -407,7 +481,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
         c->radiance.bytes = plane_bytes * batch;
     }
     const int n_batches = (n_passes + batch - 1) / batch;
-    const bool timed = !no_alloc || (int)c->ev.size() >= 2 * n_batches;     // events are created by the allocating path only
+    const bool timed = !no_alloc;      // pt_render_static records no timing events (they could not be read back after a graph capture)
     while (!no_alloc && (int)c->ev.size() < 2 * n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev.push_back(e); }
     SceneView sv = scene_view(c);
     c->n_timed = 0;
@@ -484,8 +558,7 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
             const unsigned grid = (unsigned)std::min<long long>((items + waves - 1) / waves, (long long)c->n_cus * per_cu);
             const size_t lds = bvh_lds_bytes(c, block);
             const BvhKernel &bk = kBvhLdsKernels[block == kBvhLdsBlockWide][c->sph_root >= 0][fused][generic_shading(sv.sh)];
-            const void *kern = bk.fn;
-            HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const void *kern = bk.fn;      // its dynamic-LDS cap was lifted once per device (allow_large_lds, pt_create)
             int n_nodes = c->bvh_n_nodes, entries = c->bvh_depth + kBvhStackExtra;
             void *args[] = {&sv, &fp, &n_nodes, &entries};
             HIPCHK(c, hipLaunchKernel(kern, dim3(grid), dim3(block), args, lds, c->stream));
@@ -515,6 +588,51 @@ int launch_trace(pt_ctx *c, int first_pass, int n_passes, int sum_mode, bool no_
         if (timed) c->n_timed = bi + 1;
     }
     if (no_alloc) c->order_dirty = true;    // the next pt_render must not trust a schedule that lives in the shared array
+    return PT_OK;
+}
+
+// pt_render / pt_render_pass / pt_render_sum with the "verify" option: every n-th call that would run a traversal kernel is
+// first done by the brute-force kernel (exact by construction: every mesh triangle behind the gate, like rt.comp:213-218)
+// from the same starting image, then by the traversal kernel, and the two images are compared bit for bit on the device.
+// A difference returns PT_E_STATE and leaves the brute-force image in place.  It turns "the traversal's skipping margins have
+// never been seen to lose a hit"  into something a user's own scene can assert, at about 4x the cost of the
+// checked call.  Counters count both renders; timing and pt_last_kernel_name are the traversal render's.
+int render_checked(pt_ctx *c, int first_pass, int n_passes, int sum_mode)
+{
+    if (!c) return PT_E_INVALID;
+    if (c->opt_verify <= 0) return launch_trace(c, first_pass, n_passes, sum_mode);
+    int rc = check_ready(c);
+    if (rc) return rc;
+    Bind b(c); HIPCHK(c, b.e);
+    if ((rc = sync_bvh(c)) != PT_OK) return rc;
+    if (pick_variant(c) < 5 || (++c->verify_calls % (unsigned)c->opt_verify) != 0) return launch_trace(c, first_pass, n_passes, sum_mode);
+    const size_t n_px = (size_t)c->width * c->height, bytes = n_px * 4 * sizeof(float);
+    HIPCHK(c, c->verify_before.ensure(bytes));
+    HIPCHK(c, c->verify_exact.ensure(bytes));
+    HIPCHK(c, c->verify_diff.ensure(sizeof(unsigned)));
+    HIPCHK(c, hipMemcpyAsync(c->verify_before.p, c->accum, bytes, hipMemcpyDeviceToDevice, c->stream));
+    const int saved = c->variant;
+    c->variant = c->n_chunks == 1 ? PT_DEFAULT_LDS_VARIANT : 1;
+    rc = launch_trace(c, first_pass, n_passes, sum_mode);
+    c->variant = saved;
+    if (rc != PT_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->verify_exact.p, c->accum, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->accum, c->verify_before.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    if ((rc = launch_trace(c, first_pass, n_passes, sum_mode)) != PT_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->verify_diff.p, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(pt_count_diff, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)c->accum,
+                       (const uint4 *)c->verify_exact.p, n_px, (unsigned *)c->verify_diff.p);
+    HIPCHK(c, hipGetLastError());
+    unsigned differing = 0;
+    HIPCHK(c, hipMemcpyAsync(&differing, c->verify_diff.p, sizeof differing, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->verify_runs++;
+    if (differing) {
+        HIPCHK(c, hipMemcpyAsync(c->accum, c->verify_exact.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        return fail(c, PT_E_STATE, "verify: %u of %zu pixels differ between the traversal kernel (%s) and the brute-force kernel for passes %d..%d; "
+                    "the image holds the brute-force result (pt_set_tuning variant 4 selects that kernel for good)", differing, n_px, c->last_kernel,
+                    first_pass, first_pass + n_passes - 1);
+    }
     return PT_OK;
 }
 
@@ -553,6 +671,12 @@ int pt_create(pt_ctx **out, int device)
         delete c;
         return PT_E_HIP;
     }
+    if ((e = allow_large_lds(device)) != hipSuccess) {
+        fail(nullptr, PT_E_HIP, "hipFuncSetAttribute(max dynamic LDS) on device %d: %s", device, hipGetErrorString(e));
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return PT_E_HIP;
+    }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     unsigned long long zero[kNumCounters] = {0};
@@ -578,6 +702,7 @@ void pt_destroy(pt_ctx *c)
     if (c->group_agree) (void)hipFree(c->group_agree);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     c->radiance.release();
+    c->verify_before.release(); c->verify_exact.release(); c->verify_diff.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -828,14 +953,14 @@ int pt_render_pass(pt_ctx *c, int pass)
 {
     if (!c) return PT_E_INVALID;
     if (pass < 1) return fail(c, PT_E_INVALID, "currAccumPass starts at 1 (src/Main.cpp:144); pass 0 would divide by zero");
-    return launch_trace(c, pass, 1, 0);
+    return render_checked(c, pass, 1, 0);
 }
 
 int pt_render(pt_ctx *c, int first_pass, int n_passes)
 {
     if (!c) return PT_E_INVALID;
     if (first_pass < 1) return fail(c, PT_E_INVALID, "currAccumPass starts at 1 (src/Main.cpp:144)");
-    return launch_trace(c, first_pass, n_passes, 0);
+    return render_checked(c, first_pass, n_passes, 0);
 }
 
 int pt_render_static(pt_ctx *c, int first_pass, int n_passes)
@@ -845,7 +970,7 @@ int pt_render_static(pt_ctx *c, int first_pass, int n_passes)
     return launch_trace(c, first_pass, n_passes, 0, true);
 }
 
-int pt_render_sum(pt_ctx *c, int first_pass, int n_passes) { if (!c) return PT_E_INVALID; return launch_trace(c, first_pass, n_passes, 1); }
+int pt_render_sum(pt_ctx *c, int first_pass, int n_passes) { if (!c) return PT_E_INVALID; return render_checked(c, first_pass, n_passes, 1); }
 
 int pt_scale_accum(pt_ctx *c, float scale, int set_alpha_one)
 {
@@ -948,7 +1073,7 @@ int pt_reset_counters(pt_ctx *c)
 int pt_last_render_ms(pt_ctx *c, float *ms, int *n_launches)
 {
     if (!c || !ms) return PT_E_INVALID;
-    if (c->n_timed < 1) return fail(c, PT_E_STATE, "no render has been launched on this stream yet");
+    if (c->n_timed < 1) return fail(c, PT_E_STATE, "no timed render on this stream yet (pt_render_static records no timing events)");
     Bind b(c); HIPCHK(c, b.e);
     float total = 0.0f;
     for (int i = 0; i < c->n_timed; i++) {
@@ -1082,8 +1207,25 @@ int pt_group_render(pt_ctx *c, int first_pass, int total_spp)
         (void)hipMemsetAsync(c->accum, 0, n_floats * sizeof(float), c->stream);
     }
     nrc = r.Reduce(c->accum, c->accum, n_floats, kNcclFloat32, kNcclSum, 0, c->group_comm, c->stream);
-    if (rc != PT_OK) return rc;
+    // Second status round, behind the reduce on the same stream: a rank whose trace failed AFTER the agreement round joined
+    // the reduce with zeros, and without this only that rank would know -- rank 0 would scale a sum that lacks its samples
+    // and return PT_OK with a darker image.  One int, all-reduce (max) of -status; every rank returns an error if any failed.
+    const int mine2 = -(rc != PT_OK ? rc : (nrc ? PT_E_HIP : PT_OK));
+    int nrc2 = 0, worst = 0;
+    hipError_t he = hipMemcpyAsync(c->group_agree, &mine2, sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (he == hipSuccess) nrc2 = r.AllReduce(c->group_agree, c->group_agree, 1, kNcclInt32, kNcclMax, c->group_comm, c->stream);
+    if (he == hipSuccess && !nrc2) he = hipMemcpyAsync(&worst, c->group_agree, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    // rank 0 also looks at the sample count the sum carries in alpha (every pass adds 1 there, pt_render_sum)
+    float alpha0 = (float)total_spp;
+    if (he == hipSuccess && c->group_rank == 0) he = hipMemcpyAsync(&alpha0, c->accum + 3, sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(c->stream);
+    if (rc != PT_OK) return rc;                      // this rank's own failure keeps its own message
     if (nrc) return fail(c, PT_E_HIP, "ncclReduce: %s", r.GetErrorString(nrc));
+    if (nrc2) return fail(c, PT_E_HIP, "ncclAllReduce (status): %s", r.GetErrorString(nrc2));
+    if (he != hipSuccess) return fail(c, PT_E_HIP, "status round after the reduce: %s", hipGetErrorString(he));
+    if (worst > 0) return fail(c, PT_E_STATE, "another rank of the group failed while tracing (status %d): the image on rank 0 lacks its samples", -worst);
+    if (c->group_rank == 0 && alpha0 != (float)total_spp)
+        return fail(c, PT_E_STATE, "the reduced image carries %.9g samples per pixel, %d were asked for", (double)alpha0, total_spp);
     if (c->group_rank == 0) return pt_scale_accum(c, 1.0f / (float)total_spp, 1);
     return PT_OK;
 }
@@ -1164,10 +1306,14 @@ int pt_set_option(pt_ctx *c, const char *name, int value)
         {"park_high", &c->opt_park_high, 0, 64}, {"park_wait", &c->opt_park_wait, 0, 1 << 20}, {"refill_min", &c->opt_refill_min, 0, 64},
         {"park_exit", &c->opt_park_exit, 0, 8}, {"ppi1_mul", &c->opt_ppi1_mul, 1, 4096}, {"ppi2_mul", &c->opt_ppi2_mul, 1, 4096},
         {"no_fused", &c->opt_no_fused, 0, 1}, {"wgs_per_cu", &c->opt_wgs_per_cu, 0, 8}, {"lds_block", &c->opt_lds_block, 0, 1024},
+        {"verify", &c->opt_verify, 0, 1 << 30}, {"verify_inject", &c->opt_verify_inject, 0, 1},
     };
     for (auto &o : opts)
         if (!std::strcmp(name, o.name)) {
             if (value < o.lo || value > o.hi) return fail(c, PT_E_INVALID, "option %s = %d outside [%d,%d]", name, value, o.lo, o.hi);
+            if (o.slot == &c->opt_lds_block && value != 0 && value != kBvhLdsBlock && value != kBvhLdsBlockWide)
+                return fail(c, PT_E_INVALID, "option lds_block = %d: 0 (automatic), %d or %d", value, kBvhLdsBlock, kBvhLdsBlockWide);
+            if (o.slot == &c->opt_verify_inject && value != *o.slot) c->nodes_dirty = true;     // the tree is uploaded again, with or without the fault
             *o.slot = value;
             return PT_OK;
         }

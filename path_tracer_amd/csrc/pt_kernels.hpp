@@ -1138,40 +1138,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
             // primary ray (rt.comp:326-333) and the bounce direction of a continuing path (rt.comp:296-305)
             if (wave_ballot(state == S_FRESH) | wave_ballot(state == S_DIR)) {
 #ifdef PT_DUMMY_VALU
-                {   // diagnostic (tools/insitu_cost.sh): PT_DUMMY_VALU extra instructions of kind PT_DUMMY_KIND per iteration; the
-                    // change of the kernel's time prices that instruction form inside the real instruction stream
-                    float dv0 = hp.x, dv1 = hp.y, dv2 = hp.z, dv3 = nrm.x;
-                    const float ds0 = fp.cam[0];
-#pragma unroll
-                    for (int dq = 0; dq < PT_DUMMY_VALU / 4; dq++) {
-#if PT_DUMMY_KIND == 0      // v_fma_f32, VGPR operands
-                        asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 1    // v_min_f32
-                        asm volatile("v_min_f32 %0, %0, %1\n v_min_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_min_f32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 2    // v_cmp_lt_f32 -> vcc
-                        asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3) : : "vcc");
-#elif PT_DUMMY_KIND == 3    // v_cndmask_b32 (vcc)
-                        asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3) : : "vcc");
-#elif PT_DUMMY_KIND == 4    // v_mul_f32 with an SGPR source
-                        asm volatile("v_mul_f32 %0, %4, %0\n v_mul_f32 %1, %4, %1\n v_mul_f32 %2, %4, %2\n v_mul_f32 %3, %4, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3) : "s"(ds0));
-#elif PT_DUMMY_KIND == 5    // v_mul_lo_u32
-                        asm volatile("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %1, %1, %2\n v_mul_lo_u32 %2, %2, %3\n v_mul_lo_u32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 6    // v_lshrrev_b32
-                        asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 7    // v_rcp_f32
-                        asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 8    // v_mul_f32, VGPR operands
-                        asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %1, %1, %2\n v_mul_f32 %2, %2, %3\n v_mul_f32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 9    // v_max3_f32
-                        asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %0\n v_max3_f32 %3, %3, %0, %1" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#elif PT_DUMMY_KIND == 10   // s_and_b64 (scalar ALU)
-                        asm volatile("s_and_b64 vcc, vcc, exec\n s_and_b64 vcc, vcc, exec\n s_and_b64 vcc, vcc, exec\n s_and_b64 vcc, vcc, exec" : : : "vcc");
-#elif PT_DUMMY_KIND == 11   // v_xor_b32
-                        asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0" : "+v"(dv0), "+v"(dv1), "+v"(dv2), "+v"(dv3));
-#endif
-                    }
-                    if (dv0 + dv1 + dv2 + dv3 == 1.2345e-30f) n_samples++;     // keeps the results alive, practically never true
-                }
+#include "../../tools/insitu_dummy.inc"      // diagnostic builds only (tools/insitu_cost.sh): extra instructions of one form, priced in situ
 #endif
                 n_samples += __popcll(wave_ballot(state == S_FRESH));
                 if (state == S_FRESH || state == S_DIR) {
@@ -1524,6 +1491,16 @@ __global__ void __launch_bounds__(kWave) pt_primary_hits_bvh(SceneView sc, Frame
     st.stack = stack + threadIdx.x;
     st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
     primary_hits_body<SLOTS>(sc, fp, st, threadIdx.x, blockIdx.x);
+}
+
+// pt_set_option("verify"): pixels whose 16 bytes differ between two RGBA32F images (bitwise, so NaNs compare like any value)
+__global__ void pt_count_diff(const uint4 *a, const uint4 *b, size_t n, unsigned *count)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool diff = false;
+    if (i < n) { const uint4 x = a[i], y = b[i]; diff = (x.x != y.x) | (x.y != y.y) | (x.z != y.z) | (x.w != y.w); }
+    const unsigned long long m = wave_ballot(diff);
+    if (m && (threadIdx.x & (kWave - 1)) == 0) atomicAdd(count, (unsigned)__popcll(m));
 }
 
 __global__ void pt_scale_kernel(float4 *accum, size_t n, float scale, int set_alpha_one)

@@ -357,6 +357,35 @@ def test_config3_at_baseline_size_64spp_8_bounces(capi):
         assert n_diff_pixels(full[y0:y0 + h, x0:x0 + w], want) == 0, (x0, y0)
 
 
+def test_config5_at_baseline_size_64spp_16_bounces(capi, cameras, scenes):
+    """BASELINE.json configs[4] on one GPU at its full size -- the mixed scene (bunny1 diffuse + specular, the 12 x 12 grid of
+    glass spheres and the large sphere of src/Main.cpp:76-92, emissive and ground triangles), 1920x1080, 64 spp, 16 bounces --
+    rendered once: counters, the kernel that ran (sphere tree, trees staged in LDS), run-to-run determinism (two renders, equal
+    CRC), and three windows compared bit for bit with the oracle: 128 x 8 on the glass grid (11 spheres under the window's
+    first rows), 128 x 8 on the bunny, 64 x 4 across the horizon."""
+    import oracle_py as O
+    sc, cam = scenes["mixed"], cameras["mixed"]
+    W, H, B, SPP = 1920, 1080, 16, 64
+    r = make(capi, sc, cam, W, H, B)
+    r.reset_counters()
+    r.render(1, SPP)
+    full = r.read_accum()
+    c = r.counters()
+    assert c["samples"] == W * H * SPP and c["segments"] > 3 * c["samples"] and c["hits"] > 2 * c["samples"]
+    assert c["bvh_sphere_tests"] > c["samples"] and c["bvh_tri_tests"] > 0 and c["mesh_tri_tests"] == 0
+    assert c["bvh_sphere_tests"] < 20 * c["segments"], "more than 20 of 145 spheres tested per segment"
+    assert r.kernel_name().startswith("pt_trace_items_bvh_lds<true, false, false, ")     # sphere tree, long launch, rt.comp's forms
+    r.reset()
+    r.render(1, SPP)
+    assert crc(r.read_accum()) == crc(full)
+    assert np.all(full[:, :, 3] == 1.0) and np.isfinite(full).all()
+    r.close()
+    o = O.Oracle(sc, cam, W, H, B)
+    for (x0, y0, w, h) in ((896, 528, 128, 8), (856, 544, 128, 8), (40, 900, 64, 4)):
+        want = o.render_region(1, SPP, x0, y0, w, h)
+        assert n_diff_pixels(full[y0:y0 + h, x0:x0 + w], want) == 0, (x0, y0)
+
+
 @pytest.mark.parametrize("n_tris", [1, 3, 5])
 def test_bvh_tiny_meshes(capi, cameras, n_tris):
     """meshes at and below the leaf size (the BVH root is then a stand-in inner node over one leaf)"""
