@@ -5,7 +5,8 @@ A "step" is one full render of the workload BASELINE.json's metric is quoted on 
 default res/meshes scene (bunny1 656 tris + light + ground), 1920x1080, 64 spp per GPU, 8 bounces,
 bench camera (1.5, 0.4, 0) yaw 0 pitch 0.  Inputs (scene, camera) are resident in HBM before the timed
 region; the result stays in HBM on rank 0.  `--config 3` / `--config 5` time BASELINE's configs[2] (1,002,528-triangle
-height field) and configs[4] (mixed materials, 145 spheres, 16 bounces) the same way; the default run also carries a short
+height field) and configs[4] (mixed materials, 145 spheres, 16 bounces) the same way, `--config 4` one GPU's share of configs[3]
+(3840x2160, 128 of the 1024 spp; at --gpus 8 it is configs[3] itself); the default run also carries a short
 measurement of both under the `extra` key.
 
 N = 1: reference semantics exactly (running mean, rt.comp:337).  N > 1: samples-per-pixel split, one
@@ -53,7 +54,10 @@ def workload(config):
         return ("configs[4]: mixed materials (bunny1 diffuse+specular, 144 glass spheres, 1 mirror-like sphere, emissive + ground "
                 "triangles), 1920x1080, 64 spp per GPU, 16 bounces, camera (1.5,0.8,1.5) yaw 45 pitch 20",
                 S.mixed_scene(), S.mixed_camera(), 1920, 1080, 64, 16)
-    raise SystemExit(f"--config {config}: choose 2, 3 or 5 (config 1 is the CPU reference case, config 4 is --config 2 at --gpus N)")
+    if config == 4:
+        return ("configs[3], one GPU's share: default res/meshes scene, 3840x2160, 128 spp per GPU (1024 spp over 8 GPUs), 8 bounces, "
+                "camera (1.5,0.4,0) yaw 0 pitch 0", S.default_scene(), S.bench_camera(), 3840, 2160, 128, 8)
+    raise SystemExit(f"--config {config}: choose 2, 3, 4 or 5 (config 1 is the CPU reference case)")
 
 
 def brute_force_flops(c, sc):
@@ -93,7 +97,8 @@ def reference_llvmpipe():
 def cpu_baseline(config, sc, cam, W, H, spp, bounces, gpu_image=None):
     """The oracle (C restatement of the reference, oracle/pt_oracle.c) timed on this host's cores on a bounded sample of
     the SAME workload, and the pixels it renders compared bit for bit with the image the GPU produced in the timed steps.
-    Config 2: every 2nd row of the frame.  Config 5 (twice the bounces, 147 more primitives): every 6th row.  Config 3: the
+    Config 2: every 2nd row of the frame.  Config 4 (4K, 128 spp): every 16th row.  Config 5 (twice the bounces, 147 more
+    primitives): every 6th row.  Config 3: the
     oracle scans all 1,002,528 triangles per gate-passing segment, so two windows of 24 x 4 pixels."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
@@ -102,7 +107,7 @@ def cpu_baseline(config, sc, cam, W, H, spp, bounces, gpu_image=None):
         regions = [(940, 500, 24, 4), (300, 700, 24, 4)]
         what = "two windows of 24 x 4 px at (940,500) and (300,700)"
     else:
-        step = 2 if config == 2 else 6
+        step = {2: 2, 4: 16, 5: 6}[config]
         regions = [(0, y, W, 1) for y in range(1, H, step)]
         what = f"rows 1,{1 + step},..,{regions[-1][1]} of the frame ({len(regions)} rows x {W} px)"
     o.render_region(1, 1, 0, regions[0][1], 8, 1)          # warm up (page in, thread pool)
@@ -128,7 +133,7 @@ def profiled_traffic(kernel_name, config):
     (profiles/<dir>/summary.json, tools/profile.sh: FETCH_SIZE with the gfx950 x2 correction + WRITE_SIZE).  bench.py
     cannot collect PMC counters itself; null when the newest profile of this config is of another kernel."""
     import glob
-    pat = {2: "r[0-9]*", 3: "c3_r*", 5: "c5_r*"}[config]
+    pat = {2: "r[0-9]*", 3: "c3_r*", 4: "c4_r*", 5: "c5_r*"}[config]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat, "summary.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -183,10 +188,16 @@ def extra_config(config, capi, torch, stream, check_oracle=True):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py as O
         img = r.read_accum()
-        x0, y0, w, h = (940, 500, 8, 2) if config == 3 else (900, 400, 128, 2)
-        want = O.Oracle(sc, cam, W, H, bounces).render_region(1, spp, x0, y0, w, h)
-        bad = int((want.view(np.uint32) != np.ascontiguousarray(img[y0:y0 + h, x0:x0 + w]).view(np.uint32)).any(-1).sum())
-        out["parity_vs_oracle"] = {"window": [x0, y0, w, h], "pixels_checked": w * h, "pixels_differing_bitwise": bad}
+        # config 3: one window of 32 x 8 px (the oracle scans all 1,002,528 triangles per gate-passing segment); config 5: the
+        # glass grid and the bunny, 128 x 4 px each
+        windows = [(940, 500, 32, 8)] if config == 3 else [(896, 528, 128, 4), (856, 544, 128, 4)]
+        o = O.Oracle(sc, cam, W, H, bounces)
+        bad = 0
+        for (x0, y0, w, h) in windows:
+            want = o.render_region(1, spp, x0, y0, w, h)
+            bad += int((want.view(np.uint32) != np.ascontiguousarray(img[y0:y0 + h, x0:x0 + w]).view(np.uint32)).any(-1).sum())
+        out["parity_vs_oracle"] = {"windows": [list(w) for w in windows], "pixels_checked": sum(w * h for (_, _, w, h) in windows),
+                                   "pixels_differing_bitwise": bad}
     r.close()
     return out
 
@@ -196,7 +207,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150, help="timed renders (default 150: a timed region of about one second)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, help="BASELINE config to time: 2 (default; the metric's), 3 or 5")
+    ap.add_argument("--config", type=int, default=2, help="BASELINE config to time: 2 (default; the metric's), 3, 4 (one GPU's share: 4K, 128 spp) or 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true", help="skip the extra (untimed) brute-force-kernel measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the short config 3 / config 5 measurements of the default run")
@@ -224,10 +235,21 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from path_tracer_amd import capi, distributed as D
+    from path_tracer_amd import distributed as D
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: path_tracer_amd has no CPU path")
+    # PT_BENCH_STUB=<module> (tests/test_bench_cpu.py only): the module's Renderer stands in for capi.Renderer and every
+    # tensor lives on the CPU, so that the N > 1 bookkeeping of this file -- process group, pass split, reduce_and_finish,
+    # reduce timing, max-over-ranks time, rank 0's line -- runs at world 2 over gloo on a machine without a GPU.  It renders
+    # nothing and measures nothing; the line says so.
+    stub = os.environ.get("PT_BENCH_STUB")
+    if stub:
+        import importlib
+        capi = importlib.import_module(stub)
+    else:
+        from path_tracer_amd import capi
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: path_tracer_amd has no CPU path")
+    dev = "cpu" if stub else "cuda"
     # rehearsal on a one-GPU box (not a measurement): PT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and swaps RCCL,
     # which refuses two ranks on one device, for gloo -- the rest of the N > 1 path is the real one
     rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
@@ -236,7 +258,8 @@ def main():
     reh_host = os.environ.get("PT_REHEARSAL_HOST_REDUCE", "1") == "1"
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    if not stub:
+        torch.cuda.set_device(local_rank)
     # PT_BENCH_FORCE_SPLIT=1: take the N > 1 code path (process group on RCCL, sum render, reduce, scale) with whatever
     # world size the launcher gave, 1 included -- how the RCCL leg is exercised on a one-GPU box (not a measurement)
     split = world > 1 or os.environ.get("PT_BENCH_FORCE_SPLIT") == "1"
@@ -244,7 +267,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
     if split:
-        if rehearsal:
+        if rehearsal or stub:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -261,9 +284,16 @@ def main():
         r.set_option(k, int(v))
     # one explicit stream for everything in a step (memset, trace, accumulate, RCCL reduce, scale): torch's
     # legacy default stream has handle 0, which pt_set_stream reads as "use the context's own stream"
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    accum = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")      # device memory owned by torch: the reduce reads it
+    if stub:
+        stream = capi.HostStream()
+        new_event = capi.HostEvent
+        device_sync = lambda: None
+    else:
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        new_event = lambda: torch.cuda.Event(enable_timing=True)
+        device_sync = torch.cuda.synchronize
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)         # device memory owned by torch: the reduce reads it
     r.set_accum_buffer(accum.data_ptr(), accum.numel() * 4)
     r.set_stream(stream.cuda_stream)
     red_ev = []                                                              # (before, after) events around the reduce + finish
@@ -296,7 +326,7 @@ def main():
                 dist.barrier()
             return
         if time_reduce and not rehearsal:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = new_event(), new_event()
             e0.record(stream)
         D.reduce_and_finish(accum, SPP * world, 0, None, r, check)           # the sample-count check synchronises: warm-up only
         if time_reduce and not rehearsal:
@@ -304,10 +334,10 @@ def main():
             red_ev.append((e0, e1))
 
     def fence():
-        torch.cuda.synchronize()
+        device_sync()
         if split:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for _ in range(a.warmup):
         step(check=True)
@@ -322,7 +352,7 @@ def main():
         durs.append(r.last_render_ms())
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")     # gloo reduces host memory
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if (rehearsal or stub) else "cuda")     # gloo reduces host memory
     if split:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -357,10 +387,11 @@ def main():
         total_samples = W * H * SPP * world * a.steps
         bounces_txt = "%d bounces" % BOUNCES
         out = {
-            "metric": "samples/sec (1080p, %s)" % bounces_txt, "value": total_samples / dt, "unit": "samples/s",
+            "metric": "samples/sec (%s, %s)" % ("1080p" if H == 1080 else "%dx%d" % (W, H), bounces_txt), "value": total_samples / dt, "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU over gloo): not a measurement",
+            "data": ("synthetic; STUB renderer on the CPU (tests): not a measurement" if stub else
+                     "synthetic" if not rehearsal else "synthetic; REHEARSAL (all ranks on one GPU over gloo): not a measurement"),
             "config": {"workload": desc, "baseline_config": a.config,
                        "width": W, "height": H, "spp_per_gpu": SPP, "spp_total": SPP * world, "max_bounces": BOUNCES,
                        "parallelism": "spp-split x%d + 1 RCCL reduce/render" % world if split else "single GPU"},
