@@ -56,11 +56,11 @@ typedef struct PtCounters {
     uint64_t waves;          /* persistent waves that ran                                       */
     uint64_t wave_ticks_sum; /* sum over waves of (last item done - wave start), 100 MHz ticks  */
     uint64_t wave_ticks_max; /* the longest such span: sum / (waves * max) = load balance       */
-    uint64_t bvh_node_visits;/* BVH variant: inner nodes fetched (two box tests each), per lane   */
+    uint64_t bvh_node_visits;/* BVH variant: inner nodes fetched, per lane (see bvh_box_tests)      */
     uint64_t bvh_tri_tests;  /* BVH variant: ray-triangle tests executed, per lane               */
     uint64_t phase_cycles[4];/* diagnostic builds (-DPT_PHASE_TIMERS=1): wave cycles in ray generation / closest hit / shading / (part of closest hit) mesh traversal; else 0 */
     uint64_t bvh_sphere_tests;/* BVH variant: ray-sphere tests executed in sphere-tree leaves (not part of bvh_tri_tests) */
-    uint64_t bvh_box_tests;  /* BVH variant: ray-box (slab) tests executed: 2 per node visit of a binary node, 4 of a 4-wide one */
+    uint64_t bvh_box_tests;  /* BVH variant: ray-box (slab) tests executed: 4 per visit of a four-wide node (2 in a PT_BVH_WIDE=0 build) */
 } PtCounters;
 
 /* --- lifetime: Renderer::Init (src/Renderer.cpp:33-140) creates the GL context + accum texture */
@@ -126,14 +126,18 @@ int pt_render_pass(pt_ctx *ctx, int pass);
  * into a per-pass radiance workspace, then folded into the image in pass order; bit-identical to
  * calling pt_render_pass for each pass. */
 int pt_render(pt_ctx *ctx, int first_pass, int n_passes);
-/* pt_render for callers that cannot allocate (no counterpart in the reference): code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  Same arguments, same image bit for bit, but it calls no hipMalloc, hipFree or
- * event/stream creation: the work-item queue, the tile schedule and the per-pass radiance workspace live in a 64 MiB array
+/* pt_render for callers that cannot allocate (no counterpart in the reference): code under HIP graph capture (tested:
+ * tests/test_zz_no_alloc.py captures a call, instantiates the graph and replays it), tight serving loops, harnesses that
+ * forbid hipMalloc.  Same arguments, same image bit for bit, but it calls no hipMalloc, hipFree, event/stream creation or
+ * function-attribute setter: the work-item queue, the tile schedule and the per-pass radiance workspace live in a 64 MiB array
  * that is part of the library's code object (one copy per GPU, held until the process ends).  Limits: at most 65,536 tiles
  * of 64 pixels (1920x1080 has 32,400); larger images return PT_E_LIMIT.  When the array holds fewer passes of the image than
  * a launch is worth, the passes are taken in short launches that keep the running mean in registers (same result).  The
- * scene must be uploaded before (uploads allocate).  All contexts on one GPU share that GPU's array: calls that overlap
- * on one GPU race (serialise them, e.g. on one stream); pt_last_render_ms reports only renders of the allocating calls. */
+ * scene must be uploaded before (uploads allocate).  All contexts on one GPU share that GPU's array: direct calls are ordered
+ * on the device by the library (one event per GPU: a call's first launch waits for the previous call's last, whatever context
+ * or stream made it, so no host synchronisation is needed between them).  A call recorded under stream capture carries no
+ * such event (an event from outside a capture cannot be waited for inside it): do not run two such graphs, or a graph and a
+ * direct call, on one GPU at the same time.  It records no timing events: pt_last_render_ms afterwards returns PT_E_STATE. */
 int pt_render_static(pt_ctx *ctx, int first_pass, int n_passes);
 /* Multi-GPU sample split (no reference counterpart; BASELINE.json north_star): adds the plain sum of
  * the 1-spp radiances of the given passes to the accumulation image (alpha += n_passes) so that
@@ -165,7 +169,12 @@ int pt_group_unique_id(char id[PT_GROUP_ID_BYTES]);
 int pt_group_init(pt_ctx *ctx, const char id[PT_GROUP_ID_BYTES], int rank, int world);
 /* collective: rank r traces its contiguous share of passes first_pass .. first_pass+total_spp-1 as a plain sum
  * (pt_render_sum semantics, accumulation image zeroed first), the sums meet on rank 0, rank 0 scales by 1/total_spp.
- * Afterwards rank 0's image is the mean of all samples (alpha 1); the other ranks' images hold their partial sums. */
+ * Afterwards rank 0's image is the mean of all samples (alpha 1); the other ranks' images hold their partial sums.
+ * Two small all-reduces frame the render: before it the ranks compare their arguments and local state, so that a rank with
+ * a missing scene or a different size makes EVERY rank return an error instead of leaving the others in the collective;
+ * after the reduce they share their status again, so that a rank whose trace failed makes every rank -- rank 0 above all --
+ * return PT_E_STATE instead of a darker image (rank 0 also checks the sample count the sum carries in alpha).  The call
+ * returns when the reduce has finished on this rank's stream (it synchronises once, to read that status). */
 int pt_group_render(pt_ctx *ctx, int first_pass, int total_spp);
 int pt_group_finalize(pt_ctx *ctx);
 
@@ -195,6 +204,15 @@ int pt_set_tuning(pt_ctx *ctx, int passes_per_item, size_t workspace_limit_bytes
  *   "no_fused" (0 | 1)       1: short launches also go through the per-pass workspace + pt_accumulate
  *   "wgs_per_cu" (0 | 1..8)  workgroups per CU of the LDS-resident traversal kernel
  *   "lds_block" (0|512|1024) force its workgroup size (falls back to variant 5 if the trees do not fit that way)
+ *   "verify" (0 | n)         exactness self-check: every n-th pt_render / pt_render_pass / pt_render_sum call that would run a
+ *                            traversal kernel is done twice from the same starting image -- by the brute-force kernel (every
+ *                            mesh triangle behind the root-AABB gate, like rt.comp:213-218: exact by construction) and by the
+ *                            traversal kernel -- and the two images are compared bit for bit on the device.  A difference
+ *                            returns PT_E_STATE (the text names the number of pixels) and leaves the brute-force image in
+ *                            place.  A checked call costs the brute-force render on top (config 2: about 4x), synchronises,
+ *                            and counts both renders in pt_get_counters.  pt_render_static and pt_group_render are not checked.
+ *   "verify_inject" (0 | 1)  test hook: 1 uploads the mesh tree with the root's child boxes shrunk to half their size, a
+ *                            deliberately wrong tree that "verify" must catch
  * Unknown names and values out of range return PT_E_INVALID. */
 int pt_set_option(pt_ctx *ctx, const char *name, int value);
 /* Host-only (no HIP device needed; for tests and tools): build the library's BVH over `tris` exactly as pt_upload_mesh

@@ -123,7 +123,7 @@ struct pt_ctx {
 
     // BVHs (pt_bvh.hpp): one tree over the mesh triangles (built by pt_upload_mesh), one over the spheres (pt_upload_scene);
     // their nodes are concatenated (mesh tree first, root 0) and uploaded by sync_bvh before the next launch
-    DevBuf bvh_nodes, bvh_tris, bvh_sph;
+    DevBuf bvh_nodes, bvh_nodes_q, bvh_tris, bvh_sph;
     std::vector<BvhNode> h_mesh_nodes, h_sph_nodes;
     bool mesh_bvh_ok = false, sph_bvh_ok = false, nodes_dirty = true;
     float mesh_scale = 0.0f, sph_scale = 0.0f; int mesh_depth = 0, sph_depth = 0;
@@ -262,7 +262,7 @@ SceneView scene_view(const pt_ctx *c)
     s.n_tris = c->n_tris;
     s.sph = (const float4 *)c->sph.p; s.sph_mat = (const uint32_t *)c->sph_mat.p; s.n_sph = c->n_sph;
     s.mats = (const PtMaterial *)c->mats.p; s.mat_fres = (const float4 *)c->mat_fres.p; s.prim_tab = (const float4 *)c->prim_tab.p;
-    s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
+    s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_nodes_q = (const float4 *)c->bvh_nodes_q.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
     s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root;
     for (int k = 0; k < 3; k++) { s.sph_bmin[k] = c->sph_bmin[k]; s.sph_bmax[k] = c->sph_bmax[k]; }
     return s;
@@ -317,7 +317,7 @@ constexpr int kBvhStackExtra = 3;
 constexpr size_t kBvhLdsLimit = 80 * 1024, kBvhLdsLimitWide = 158 * 1024;
 size_t bvh_lds_bytes(const pt_ctx *c, int block)
 {
-    return (size_t)c->bvh_n_nodes * 64 + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
+    return (size_t)c->bvh_n_nodes * (kBvhNodeVecs * 16) + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
            + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * (size_t)block;
 }
 // The LDS-resident traversal kernels take more dynamic LDS than a kernel may by default: the cap is lifted for every
@@ -369,32 +369,70 @@ int sync_bvh(pt_ctx *c)
     c->bvh_ok = (c->n_mesh == 0 || c->mesh_bvh_ok) && (mesh || sph);
     c->sph_root = -1; c->bvh_n_nodes = 0; c->bvh_depth = 0; c->bvh_scale = 0.0f;
     if (c->bvh_ok) {
+        // stack entries a lane can need below the roots: the binary tree pushes one sibling per level, the four-wide collapse up
+        // to three per node (pt_bvh.hpp collapse_bvh4 computes the exact bound)
+        int need_mesh = mesh ? c->mesh_depth : 0, need_sph = sph ? c->sph_depth : 0;
+        const void *data; size_t bytes;
         std::vector<BvhNode> all;
-        if (mesh) all = c->h_mesh_nodes;
-        if (sph) {
-            const int base = (int)all.size();
-            c->sph_root = base;
-            for (BvhNode nd : c->h_sph_nodes) {
-                if (nd.left >= 0) nd.left += base;
-                if (nd.right >= 0) nd.right += base;
-                all.push_back(nd);
+        std::vector<BvhNode4> wide;
+        std::vector<BvhNode4Q> quant;          // staging vectors live until the synchronisation below
+        if (kBvhWide) {
+            Bvh4 m4, s4;
+            if (mesh) { collapse_bvh4(c->h_mesh_nodes, m4, 0); need_mesh = m4.stack_need; }
+            if (sph) { c->sph_root = (int)m4.nodes.size(); collapse_bvh4(c->h_sph_nodes, s4, c->sph_root); need_sph = s4.stack_need; }
+            wide = std::move(m4.nodes);
+            wide.insert(wide.end(), s4.nodes.begin(), s4.nodes.end());
+            if (c->opt_verify_inject && mesh && !wide.empty()) {
+                // test hook for the "verify" option: a deliberately WRONG tree -- the root's child boxes shrunk to half their
+                // size -- so that the traversal skips triangles it must not skip
+                BvhNode4 &r0 = wide[0];
+                float *lo[3] = {r0.mnx, r0.mny, r0.mnz}, *hi[3] = {r0.mxx, r0.mxy, r0.mxz};
+                for (int i = 0; i < 4; i++)
+                    for (int k = 0; k < 3; k++) {
+                        if (r0.child[i] == kBvhNoChild) continue;
+                        const float mid = 0.5f * (lo[k][i] + hi[k][i]), half = 0.25f * (hi[k][i] - lo[k][i]);
+                        lo[k][i] = mid - half; hi[k][i] = mid + half;
+                    }
             }
-        }
-        if (c->opt_verify_inject && mesh && !all.empty()) {
-            // test hook for the "verify" option: a deliberately WRONG tree -- the root's child boxes shrunk to half their
-            // size -- so that the traversal skips triangles it must not skip
-            BvhNode &r0 = all[0];
-            for (int k = 0; k < 3; k++) {
-                const float lc = 0.5f * (r0.lmin[k] + r0.lmax[k]), lh = 0.25f * (r0.lmax[k] - r0.lmin[k]);
-                const float rc = 0.5f * (r0.rmin[k] + r0.rmax[k]), rh = 0.25f * (r0.rmax[k] - r0.rmin[k]);
-                r0.lmin[k] = lc - lh; r0.lmax[k] = lc + lh; r0.rmin[k] = rc - rh; r0.rmax[k] = rc + rh;
+            data = wide.data(); bytes = wide.size() * sizeof(BvhNode4);
+            c->bvh_n_nodes = (int)wide.size();
+            // the 64-byte form, for the kernel that reads the tree in place (variant 5)
+            quant.resize(wide.size());
+            bool q_ok = true;
+            for (size_t i = 0; i < wide.size() && q_ok; i++) q_ok = quantise_bvh4(wide[i], quant[i]);
+            if (!q_ok) { need_mesh = need_sph = kBvhMaxDepth; }       // refused below: brute force
+            else HIPCHK(c, c->bvh_nodes_q.upload(quant.data(), quant.size() * sizeof(BvhNode4Q), c->stream));
+        } else {
+            if (mesh) all = c->h_mesh_nodes;
+            if (sph) {
+                const int base = (int)all.size();
+                c->sph_root = base;
+                for (BvhNode nd : c->h_sph_nodes) {
+                    if (nd.left >= 0) nd.left += base;
+                    if (nd.right >= 0) nd.right += base;
+                    all.push_back(nd);
+                }
             }
+            if (c->opt_verify_inject && mesh && !all.empty()) {
+                BvhNode &r0 = all[0];
+                for (int k = 0; k < 3; k++) {
+                    const float lc = 0.5f * (r0.lmin[k] + r0.lmax[k]), lh = 0.25f * (r0.lmax[k] - r0.lmin[k]);
+                    const float rc = 0.5f * (r0.rmin[k] + r0.rmax[k]), rh = 0.25f * (r0.rmax[k] - r0.rmin[k]);
+                    r0.lmin[k] = lc - lh; r0.lmax[k] = lc + lh; r0.rmin[k] = rc - rh; r0.rmax[k] = rc + rh;
+                }
+            }
+            data = all.data(); bytes = all.size() * sizeof(BvhNode);
+            c->bvh_n_nodes = (int)all.size();
         }
-        HIPCHK(c, c->bvh_nodes.upload(all.data(), all.size() * sizeof(BvhNode), c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->bvh_n_nodes = (int)all.size();
-        c->bvh_depth = std::max(mesh ? c->mesh_depth : 0, sph ? c->sph_depth : 0) + 1;   // + the other tree's root on the stack
-        c->bvh_scale = std::max(mesh ? c->mesh_scale : 0.0f, sph ? c->sph_scale : 0.0f);
+        if (std::max(need_mesh, need_sph) + 1 > kBvhMaxDepth) {
+            // deeper than the traversal stacks are sized for (the test-only probe kernel's is static): brute force instead
+            c->bvh_ok = false; c->sph_root = -1; c->bvh_n_nodes = 0;
+        } else {
+            HIPCHK(c, c->bvh_nodes.upload(data, bytes, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->bvh_depth = std::max(need_mesh, need_sph) + 1;   // + the other tree's root on the stack
+            c->bvh_scale = std::max(mesh ? c->mesh_scale : 0.0f, sph ? c->sph_scale : 0.0f);
+        }
     }
     c->nodes_dirty = false;
     return PT_OK;
@@ -697,7 +735,7 @@ void pt_destroy(pt_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->group_comm) (void)pt_group_finalize(c);
     for (DevBuf *b : {&c->mesh_soa, &c->mesh_p1, &c->mesh_e1, &c->mesh_e2, &c->mesh_nrm, &c->tri_p1, &c->tri_e1, &c->tri_e2,
-                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->mat_fres, &c->prim_tab, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_tris, &c->bvh_sph}) b->release();
+                      &c->tri_nrm, &c->sph, &c->sph_mat, &c->mats, &c->mat_fres, &c->prim_tab, &c->counters, &c->queue, &c->tile_weights, &c->tile_order, &c->class_count, &c->bvh_nodes, &c->bvh_nodes_q, &c->bvh_tris, &c->bvh_sph}) b->release();
     if (c->accum_own) (void)hipFree(c->accum_own);
     if (c->group_agree) (void)hipFree(c->group_agree);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -1292,6 +1330,46 @@ int pt_bvh_selftest(const PtTriangle *tris, int n, int *n_nodes, int *depth, int
     const int expect = n <= kLeafMax ? 2 : 1;
     for (int i = 0; i < n; i++) if (seen[i] != expect) ok = false;
     if (!ok) return PT_E_STATE;
+    // the four-wide collapse the kernels traverse (collapse_bvh4): the same leaves, each reached exactly once; every child box
+    // contains its subtree; unused slots carry the far box and kBvhNoChild; the stack bound covers the deepest chain of pushes
+    {
+        Bvh4 w4;
+        collapse_bvh4(bvh.nodes, w4, 0);
+        if (w4.nodes.empty() || w4.nodes.size() > bvh.nodes.size()) return PT_E_STATE;
+        std::vector<int> seen4(n, 0);
+        bool ok4 = true;
+        struct Walk4 {
+            const Bvh4 &w; const Bvh &b; const PtTriangle *tris; int n; std::vector<int> &seen; bool &ok; int max_push = 0;
+            bvh_detail::Box walk(int code, int pushed, int d)
+            {
+                bvh_detail::Box box; box.reset();
+                if (d > kBvhMaxDepth + 1) { ok = false; return box; }
+                if (code < 0) {
+                    const int c = ~code, first = c >> 3, cnt = (c & 7) + 1;
+                    if (code == kBvhNoChild || first < 0 || first + cnt > n) { ok = false; return box; }
+                    for (int j = first; j < first + cnt; j++) { const int i = b.order[j]; seen[i]++; box.grow(tris[i].p1); box.grow(tris[i].p2); box.grow(tris[i].p3); }
+                    return box;
+                }
+                if (code >= (int)w.nodes.size()) { ok = false; return box; }
+                const BvhNode4 &nd = w.nodes[code];
+                int used = 0;
+                for (int i = 0; i < 4; i++) if (nd.child[i] != kBvhNoChild) used++;
+                if (used < 2) ok = false;
+                max_push = std::max(max_push, pushed + used - 1);
+                for (int i = 0; i < 4; i++) {
+                    if (nd.child[i] == kBvhNoChild) { if (nd.mnx[i] != kBvhFarBox || nd.mxz[i] != kBvhFarBox || i < used) ok = false; continue; }
+                    const bvh_detail::Box sub = walk(nd.child[i], pushed + used - 1, d + 1);
+                    const float mn[3] = {nd.mnx[i], nd.mny[i], nd.mnz[i]}, mx[3] = {nd.mxx[i], nd.mxy[i], nd.mxz[i]};
+                    for (int k = 0; k < 3; k++) if (!(mn[k] <= sub.mn[k] && mx[k] >= sub.mx[k])) ok = false;
+                    box.grow(sub);
+                }
+                return box;
+            }
+        } w4k{w4, bvh, tris, n, seen4, ok4};
+        w4k.walk(0, 0, 0);
+        for (int i = 0; i < n; i++) if (seen4[i] != expect) ok4 = false;
+        if (!ok4 || w4k.max_push != w4.stack_need) return PT_E_STATE;
+    }
     if (n_nodes) *n_nodes = (int)bvh.nodes.size();
     if (depth) *depth = bvh.depth;
     if (max_leaf) *max_leaf = biggest;

@@ -32,6 +32,44 @@ struct Bvh {
     int depth = 0;
 };
 
+// 128-byte four-wide inner node, what the traversal kernels read (PT_BVH_WIDE): the boxes of up to four children, component by
+// component (so that child k is lane k of six float4 loads), and their codes (same encoding as BvhNode's).  An unused slot
+// holds a box far outside every scene -- both corners at (kBvhFarBox, kBvhFarBox, kBvhFarBox); uploads refuse coordinates beyond
+// 1e18 -- so the slab test rejects it like any box the ray misses, without a test of its own: per axis both planes give the same
+// t, either > every hit distance or < 0.  (An "empty" box with min > max would NOT do: the test sorts each axis' pair.)  Its
+// code is kBvhNoChild.  One node = one 128-byte cache line
+// where the tree lives in global memory: a node visit is ONE dependent fetch for four children instead of two for two each.
+struct BvhNode4 {
+    float mnx[4], mny[4], mnz[4], mxx[4], mxy[4], mxz[4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(BvhNode4) == 128, "BvhNode4 is 8 x float4");
+constexpr int32_t kBvhNoChild = (int32_t)0x80000000;      // == the traversal's kTravDone: never followed (its box is empty)
+
+// The same node in 64 bytes, for trees that live in global memory (traversal variant 5): child boxes as 8-bit offsets from the
+// node's own corner `o`, in steps of 2^e per axis.  A node visit is then FOUR 16-byte loads per lane instead of seven -- the
+// vector-memory pipeline, not arithmetic, bounds the traversal of a tree that does not fit in LDS -- and the
+// whole tree is half as large in L2.  Quantisation is conservative: the box a lane reconstructs, fmaf(q, 2^e, o) per plane --
+// the very operation quantise_bvh4 checks with -- contains the exact box; boxes only ever decide what may be SKIPPED.
+//   float4 0: o.x, o.y, o.z, bits(ex | ey << 8 | ez << 16)   (e as the biased exponent byte of the float 2^e)
+//   float4 1: child codes
+//   float4 2: qmin.x of children 0..3 (one byte each) | qmin.y | qmin.z | qmax.x      float4 3: qmax.y | qmax.z | - | -
+struct BvhNode4Q {
+    float o[3];
+    uint32_t exps;
+    int32_t child[4];
+    uint8_t qmn[3][4], qmx[3][4];
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode4Q) == 64, "BvhNode4Q is 4 x float4");
+
+struct Bvh4 {
+    std::vector<BvhNode4> nodes;      // nodes[0] is the root
+    int stack_need = 0;               // most entries one lane's stack can hold at once (every visit may push all but one child)
+    int depth = 0;
+};
+
 namespace bvh_detail {
 
 struct Box {
@@ -155,6 +193,93 @@ inline void build_from_refs(bvh_detail::Builder &b, Bvh &out)
         return;
     }
     b.build(0, n, 0);
+}
+
+// Collapse the binary tree into a four-wide one: a node starts with the two children of a binary node and, while it has a free
+// slot, replaces the inner child with the largest box by that child's own two children.  Leaves, their order and every box are
+// the binary tree's: the set of triangles a ray can reach is unchanged, only the number of steps to reach them is.
+// `base` is added to every inner child index (the sphere tree's nodes follow the mesh tree's in one array).
+inline void collapse_bvh4(const std::vector<BvhNode> &bin, Bvh4 &out, int base = 0)
+{
+    using bvh_detail::Box;
+    out.nodes.clear(); out.stack_need = 0; out.depth = 0;
+    if (bin.empty()) return;
+    struct Slot { Box b; int code; };
+    struct Rec {
+        const std::vector<BvhNode> &bin; Bvh4 &out; int base;
+        static void kids(const BvhNode &n, Slot &l, Slot &r)
+        {
+            for (int k = 0; k < 3; k++) { l.b.mn[k] = n.lmin[k]; l.b.mx[k] = n.lmax[k]; r.b.mn[k] = n.rmin[k]; r.b.mx[k] = n.rmax[k]; }
+            l.code = n.left; r.code = n.right;
+        }
+        // returns the wide node's index; need = stack entries a traversal below it can hold, depth = levels below it
+        int make(int bi, int depth, int &need)
+        {
+            Slot s[4]; int ns = 2;
+            kids(bin[bi], s[0], s[1]);
+            while (ns < 4) {
+                int pick = -1; float area = -1.0f;
+                for (int i = 0; i < ns; i++) if (s[i].code >= 0 && s[i].b.half_area() > area) { area = s[i].b.half_area(); pick = i; }
+                if (pick < 0) break;
+                Slot l, r;
+                kids(bin[s[pick].code], l, r);
+                s[pick] = l; s[ns++] = r;
+            }
+            const int me = (int)out.nodes.size();
+            out.nodes.emplace_back();
+            out.depth = std::max(out.depth, depth + 1);
+            int below = 0, codes[4];
+            for (int i = 0; i < ns; i++) {
+                codes[i] = s[i].code;
+                if (s[i].code >= 0) { int nd = 0; codes[i] = make(s[i].code, depth + 1, nd) + base; below = std::max(below, nd); }
+            }
+            BvhNode4 &w = out.nodes[me];
+            for (int i = 0; i < 4; i++) {
+                const bool used = i < ns;
+                w.mnx[i] = used ? s[i].b.mn[0] : kBvhFarBox; w.mny[i] = used ? s[i].b.mn[1] : kBvhFarBox; w.mnz[i] = used ? s[i].b.mn[2] : kBvhFarBox;
+                w.mxx[i] = used ? s[i].b.mx[0] : kBvhFarBox; w.mxy[i] = used ? s[i].b.mx[1] : kBvhFarBox; w.mxz[i] = used ? s[i].b.mx[2] : kBvhFarBox;
+                w.child[i] = used ? codes[i] : kBvhNoChild; w.pad[i] = 0;
+            }
+            need = (ns - 1) + below;       // this visit leaves at most ns - 1 siblings on the stack while the traversal goes on below
+            return me;
+        }
+    } rec{bin, out, base};
+    int need = 0;
+    rec.make(0, 0, need);
+    out.stack_need = need;
+}
+
+// 64-byte form of a four-wide node; returns false if a box cannot be represented (never for finite boxes within +-1e18)
+inline bool quantise_bvh4(const BvhNode4 &w, BvhNode4Q &q)
+{
+    std::memset(&q, 0, sizeof q);
+    const float *mn[3] = {w.mnx, w.mny, w.mnz}, *mx[3] = {w.mxx, w.mxy, w.mxz};
+    for (int k = 0; k < 3; k++) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < 4; i++) if (w.child[i] != kBvhNoChild) { lo = std::min(lo, mn[k][i]); hi = std::max(hi, mx[k][i]); }
+        if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
+        // smallest step 2^e with (hi - lo) / 2^e <= 253: two codes stay free for the outward corrections below
+        int e = -126;
+        const double ext = (double)hi - (double)lo;
+        if (ext > 0.0) { int ex; std::frexp(ext / 253.0, &ex); e = std::max(-126, ex); }      // 2^ex > ext / 253 >= 2^(ex-1)
+        if (e > 127) return false;
+        const float step = std::ldexp(1.0f, e);
+        q.o[k] = lo;
+        q.exps |= (uint32_t)(e + 127) << (8 * k);
+        for (int i = 0; i < 4; i++) {
+            if (w.child[i] == kBvhNoChild) { q.qmn[k][i] = 255; q.qmx[k][i] = 0; continue; }
+            int a = (int)std::floor(((double)mn[k][i] - (double)lo) / (double)step);
+            int b = (int)std::ceil(((double)mx[k][i] - (double)lo) / (double)step);
+            a = std::min(std::max(a, 0), 255); b = std::min(std::max(b, 0), 255);
+            // the lane evaluates fmaf(q, step, o) in float: step the codes outwards until THAT value encloses the exact plane
+            while (a > 0 && std::fmaf((float)a, step, lo) > mn[k][i]) a--;
+            while (b < 255 && std::fmaf((float)b, step, lo) < mx[k][i]) b++;
+            if (std::fmaf((float)a, step, lo) > mn[k][i] || std::fmaf((float)b, step, lo) < mx[k][i]) return false;
+            q.qmn[k][i] = (uint8_t)a; q.qmx[k][i] = (uint8_t)b;
+        }
+    }
+    for (int i = 0; i < 4; i++) q.child[i] = w.child[i];
+    return true;
 }
 
 inline void build_bvh(const PtTriangle *tris, int n, Bvh &out)

@@ -35,6 +35,20 @@ constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
 constexpr int kNumCounters = 18;
 constexpr int kBvhStack = kBvhMaxDepth + 1;   // per-lane traversal stack entries (one extra: the sphere tree's root under the mesh tree)
+// PT_POSTPONE = 1: lanes carry one leaf along untested while they go on through the nodes (see the traversal phase of
+// trace_items_body_bvh); a node step is taken while n_node * DEN >= n_leaf * NUM (lanes that can visit a node vs lanes that
+// hold a leaf).  Needs the four-wide tree.
+#ifndef PT_POSTPONE
+#define PT_POSTPONE 1
+#endif
+#ifndef PT_POSTPONE_NUM
+#define PT_POSTPONE_NUM 1
+#endif
+#ifndef PT_POSTPONE_DEN
+#define PT_POSTPONE_DEN 1
+#endif
+constexpr bool kPostpone = PT_POSTPONE != 0 && kBvhWide;
+constexpr int kTravDone = (int)0x80000000;      // traversal position of a lane that is not traversing; the bottom of every stack; the code of an unused child slot
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
 // PtShadingParams (include/pt_hip.h: the literals in which rt.frag differs from rt.comp) as the kernels take them:
@@ -77,7 +91,8 @@ struct SceneView {
     const float4 *prim_tab;   // [n_mesh + n_tris][4]: (p1 | material bits, e1, e2, normal) by canonical id -- the traversal kernels' only triangle table
     const float4 *mat_fres;   // per material, computed on the host with the same IEEE operations: 1/ior, r0 and n1/n2 of a front-face hit (pt_math.hpp fresnel_reflect_amount)
     // BVH over the mesh triangles (pt_bvh.hpp), used by the traversal variant
-    const float4 *bvh_nodes;  // 4 x float4 per inner node: both child boxes + child codes
+    const float4 *bvh_nodes;  // kBvhNodeVecs x float4 per inner node: child boxes + child codes (pt_bvh.hpp BvhNode4 / BvhNode); staged into LDS by variant 6
+    const float4 *bvh_nodes_q; // the four-wide nodes in their 64-byte quantised form (BvhNode4Q), read in place by variant 5
     const float4 *bvh_tris;   // 3 x float4 per triangle in leaf order: (p1, bits(original index)), e1, e2
     float bvh_scale;          // largest |coordinate| of the mesh and the spheres (for the traversal's safety margin)
     const float4 *bvh_sph;    // sphere tree leaves, 2 x float4 per sphere in leaf order: (centre, radius), (bits(sphere index), -, -, -)
@@ -350,6 +365,25 @@ struct BvhStore {
         const float4 k = n[3];
         kl = __float_as_int(k.x); kr = __float_as_int(k.y);
     }
+    // four-wide node in its 64-byte quantised form (pt_bvh.hpp BvhNode4Q): four loads per lane, then every plane is rebuilt
+    // as fmaf(q, 2^e, o) (the byte extraction + conversion compiles to one v_cvt_f32_ubyteN) -- the operation the host checked its outward rounding with.  Child k is component k of the six
+    // box vectors.  An unused slot has no box of its own here: the caller tests its code (kChildTest).
+    static constexpr bool kChildTest = true;
+    const float4 *nodes_q;
+    __device__ __forceinline__ void node4(int i, float4 &mnx, float4 &mny, float4 &mnz, float4 &mxx, float4 &mxy, float4 &mxz, int &c0, int &c1, int &c2, int &c3) const
+    {
+        const float4 *n = nodes_q + 4 * (size_t)i;
+        const float4 o = n[0], k = n[1], qa = n[2];
+        const float2 qb = *reinterpret_cast<const float2 *>(n + 3);
+        c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
+        const unsigned ex = __float_as_uint(o.w);
+        const float sx = __uint_as_float((ex & 0xffu) << 23), sy = __uint_as_float((ex & 0xff00u) << 15), sz = __uint_as_float((ex & 0xff0000u) << 7);
+#define PT_DEQ(word, step, org) make_float4(fmaf((float)(((word) >> 0) & 0xffu), step, org), fmaf((float)(((word) >> 8) & 0xffu), step, org), \
+                                            fmaf((float)(((word) >> 16) & 0xffu), step, org), fmaf((float)(((word) >> 24) & 0xffu), step, org))
+        mnx = PT_DEQ(__float_as_uint(qa.x), sx, o.x); mny = PT_DEQ(__float_as_uint(qa.y), sy, o.y); mnz = PT_DEQ(__float_as_uint(qa.z), sz, o.z);
+        mxx = PT_DEQ(__float_as_uint(qa.w), sx, o.x); mxy = PT_DEQ(__float_as_uint(qb.x), sy, o.y); mxz = PT_DEQ(__float_as_uint(qb.y), sz, o.z);
+#undef PT_DEQ
+    }
     __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
     {
         const float4 *t = tris + 3 * (size_t)j;
@@ -374,6 +408,16 @@ struct BvhLdsStore {
         a = f4(n[0]); b = f4(n[1]); c = f4(n[2]);
         const f4v k = n[3];
         kl = __float_as_int(k.x); kr = __float_as_int(k.y);
+    }
+    // four-wide node, float boxes (pt_bvh.hpp BvhNode4, 128 B): child k is component k of the six box vectors; an unused slot
+    // carries a box no ray meets
+    static constexpr bool kChildTest = false;
+    __device__ __forceinline__ void node4(int i, float4 &mnx, float4 &mny, float4 &mnz, float4 &mxx, float4 &mxy, float4 &mxz, int &c0, int &c1, int &c2, int &c3) const
+    {
+        lds_cf4v *n = nodes + 8 * i;
+        mnx = f4(n[0]); mny = f4(n[1]); mnz = f4(n[2]); mxx = f4(n[3]); mxy = f4(n[4]); mxz = f4(n[5]);
+        const f4v k = n[6];
+        c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
     }
     __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
     {
@@ -428,16 +472,41 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, Store &st, bool
     unsigned *stk = st.stack;
     int sp = 0, cur = 0;
     for (;;) {
+        int next;
+        n_nodes++;
+        const float lim = fmaf(best_t, 1.001f, delta);
+        if constexpr (kBvhWide) {
+            // four children, visited in slot order (this routine serves the test-only primary-hit probe; the trace kernels'
+            // traversal phase goes to the nearest child first)
+            float4 mnx, mny, mnz, mxx, mxy, mxz;
+            int cc[4];
+            st.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, cc[0], cc[1], cc[2], cc[3]);
+            const float bx[4][6] = {{mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x}, {mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y},
+                                    {mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z}, {mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w}};
+            bool have = false;
+            next = 0;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                float t0, t1;
+                slab_test(bx[k][0], bx[k][1], bx[k][2], bx[k][3], bx[k][4], bx[k][5], olo, ohi, inv, t0, t1);
+                if (t0 <= t1 && t0 <= lim && (!Store::kChildTest || cc[k] != kTravDone)) {
+                    if (have) { stk[sp * kWave] = (unsigned)next; sp++; }
+                    next = cc[k]; have = true;
+                }
+            }
+            if (!have) {
+                if (sp == 0) break;
+                sp--;
+                next = (int)stk[sp * kWave];
+            }
+        } else {
         float4 a, b, c;
         int kl, kr;
         st.node(cur, a, b, c, kl, kr);
-        n_nodes++;
         float l0, l1, r0, r1;
         slab_test(a.x, a.y, a.z, a.w, b.x, b.y, olo, ohi, inv, l0, l1);
         slab_test(b.z, b.w, c.x, c.y, c.z, c.w, olo, ohi, inv, r0, r1);
-        const float lim = fmaf(best_t, 1.001f, delta);
         const bool hl = l0 <= l1 && l0 <= lim, hr = r0 <= r1 && r0 <= lim;
-        int next;
         if (hl && hr) {
             const bool left_first = l0 <= r0;
             next = left_first ? kl : kr;
@@ -451,6 +520,7 @@ __device__ __forceinline__ void bvh_closest(const SceneView &sc, Store &st, bool
             if (sp == 0) break;
             sp--;
             next = (int)stk[sp * kWave];
+        }
         }
         bool done = false;
         while (next < 0) {
@@ -849,7 +919,6 @@ __device__ __forceinline__ bool closer_hit(float t, int id, float best_t, int be
 }
 
 enum : int { S_DEAD = 0, S_FRESH = 1, S_TRACE = 2, S_MESH = 3, S_READY = 4, S_DIR = 5 };
-constexpr int kTravDone = (int)0x80000000;      // traversal position of a lane that is not traversing; also the bottom of every stack
 
 // SPH: the scene has a sphere tree (compile-time, so scenes without spheres carry none of its code or registers).
 // SHORT: launches of a few passes (interactive use): items are dealt round-robin to the waves instead of pulled from the
@@ -899,6 +968,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     int s_id = -1, best_id = -1;
     // resumable traversal state (see the traversal phase): position `cur`, stack height `sp` (slot 0 = kTravDone for good)
     int cur = kTravDone, sp = 1;
+    int pend = kTravDone;              // kPostpone: the leaf this lane carries along untested (a leaf code), kTravDone: none
     stk[0] = (unsigned)kTravDone;
     v3 inv = V(0, 0, 0);
     float delta = 0.0f;
@@ -981,6 +1051,121 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 const int exit_at = n_other > 0 ? (n_mesh * fp.park_exit) >> 3 : 0;
                 const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
                 const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
+                // One leaf's worth of primitives, read from `code_neg` (a leaf code): a sphere, or up to two triangles (independent
+                // tests: the second hides the first's latencies).  Returns how many were used.
+                auto test_leaf = [&](int code_neg) -> int {
+                    const int code = ~code_neg, first = (code & (kSphereLeaf - 1)) >> 3, cnt = (code & 7) + 1;
+                    if (SPH && (code & kSphereLeaf) != 0) {
+                        // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
+                        float4 cr;
+                        int si;
+                        st.sphere(first, cr, si);
+                        float t; bool front;
+                        const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front, sc.sh.hit_limit, sh_xyz);
+                        const int id = sc.n_mesh + sc.n_tris + si;
+                        n_sph_tests++;
+                        const bool take = has & closer_hit(t, id, best_t, best_id);
+                        best_t = take ? t : best_t; best_id = take ? id : best_id;
+                        return 1;
+                    }
+                    const bool two = cnt >= 2;
+                    float4 p1, e1, e2, q1, f1, f2;
+                    st.tri(first, p1, e1, e2);
+                    st.tri(two ? first + 1 : first, q1, f1, f2);
+                    float t, det, t2, det2;
+                    bool bad = false;
+                    bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad, sc.sh.hit_limit);
+                    bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad, sc.sh.hit_limit);
+                    if (__builtin_expect(bad, 0)) {
+                        has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, sc.sh.hit_limit);
+                        has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, sc.sh.hit_limit);
+                    }
+                    const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
+                    n_bvh_tests += two ? 2 : 1;
+                    const bool take = has & closer_hit(t, id, best_t, best_id);
+                    best_t = take ? t : best_t; best_id = take ? id : best_id;
+                    const bool take2 = (two & has2) & closer_hit(t2, id2, best_t, best_id);
+                    best_t = take2 ? t2 : best_t; best_id = take2 ? id2 : best_id;
+                    return two ? 2 : 1;
+                };
+                if constexpr (kPostpone) {
+                // A lane that reaches a leaf does not stop for it: it takes the leaf along (`pend`) and goes on through the nodes
+                // until it stands on a second one.  Node steps then run for every lane that is not blocked on a second leaf, and
+                // a leaf step finds a leaf in (nearly) every lane -- instead of either kind of step idling the lanes that want the
+                // other (Aila & Laine's "speculative traversal", inside the wave's majority vote).  The hit a postponed leaf would
+                // have found cannot prune the nodes visited in between, so a few more nodes are visited; the set of primitives
+                // tested can only grow, and the result -- the lexicographic minimum of (t, id) -- is the same.
+                // Invariant between steps: cur >= 0 (a node to visit), or cur == kTravDone (nothing left on the stack), or cur is a
+                // leaf AND pend holds another (blocked until a leaf step).  Finished: cur == kTravDone and pend == kTravDone.
+                for (;;) {
+                    const unsigned long long m_node = wave_ballot(cur >= 0), m_leaf = wave_ballot(pend != kTravDone);
+                    const int n = __popcll(m_node | m_leaf);
+                    if (n <= exit_at) break;
+                    const int n_node = __popcll(m_node), n_leaf = __popcll(m_leaf);
+                    const bool was_busy = (cur >= 0) | (pend != kTravDone);
+                    // the top of the stack and the entry below it, read speculatively beside the step's own data (slot 0 holds
+                    // kTravDone for good; the indices are clamped for lanes that are not traversing, whose sp may be 0)
+                    const int top = (int)stk[max(sp - 1, 0) * kWave], below = (int)stk[max(sp - 2, 0) * kWave];
+                    if (n_node * PT_POSTPONE_DEN >= n_leaf * PT_POSTPONE_NUM) {
+                        PT_COUNT(cyc_trace, 1);
+                        if (cur >= 0) {
+                            float4 mnx, mny, mnz, mxx, mxy, mxz;
+                            int c0, c1, c2, c3;
+                            st.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, c0, c1, c2, c3);
+                            n_bvh_nodes++;
+                            const float lim = fmaf(best_t, 1.001f, delta);
+                            float a0, a1;
+                            slab_test_fma(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, nlo, nhi, inv, a0, a1);
+                            const bool h0 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;      // slots 0 and 1 are always in use
+                            const float e0 = a0;
+                            slab_test_fma(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, nlo, nhi, inv, a0, a1);
+                            const bool h1 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;
+                            const float e1 = a0;
+                            slab_test_fma(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, nlo, nhi, inv, a0, a1);
+                            const bool h2 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c2 != kTravDone);
+                            const float e2 = a0;
+                            slab_test_fma(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, nlo, nhi, inv, a0, a1);
+                            const bool h3 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c3 != kTravDone);
+                            const float e3 = a0;
+                            float et = h0 ? e0 : kInfinity * 4.0f;
+                            int ec = c0;
+                            const bool b1 = h1 && e1 < et; et = b1 ? e1 : et; ec = b1 ? c1 : ec;
+                            const bool b2 = h2 && e2 < et; et = b2 ? e2 : et; ec = b2 ? c2 : ec;
+                            const bool b3 = h3 && e3 < et; ec = b3 ? c3 : ec;
+                            const bool any = h0 | h1 | h2 | h3;
+                            const bool p0 = h0 & (b1 | b2 | b3), p1 = h1 & (!b1 | b2 | b3), p2 = h2 & (!b2 | b3), p3 = h3 & !b3;
+                            // the pushes, and in `tp` what is on top of the stack after them
+                            int s = sp, tp = top;
+                            stk[s * kWave] = (unsigned)c0; s += p0 ? 1 : 0; tp = p0 ? c0 : tp;
+                            stk[s * kWave] = (unsigned)c1; s += p1 ? 1 : 0; tp = p1 ? c1 : tp;
+                            stk[s * kWave] = (unsigned)c2; s += p2 ? 1 : 0; tp = p2 ? c2 : tp;
+                            stk[s * kWave] = (unsigned)c3; s += p3 ? 1 : 0; tp = p3 ? c3 : tp;
+                            const int next = any ? ec : top;             // no child hit: pop
+                            const int next_top = any ? tp : below;
+                            const int next_sp = any ? s : sp - 1;
+                            // the new position is a leaf and none is pending: take it along and pop
+                            const bool stash = next < 0 && next != kTravDone && pend == kTravDone;
+                            pend = stash ? next : pend;
+                            cur = stash ? next_top : next;
+                            sp = stash ? next_sp - 1 : next_sp;
+                        }
+                    } else {
+                        PT_COUNT(cyc_shade, 1);
+                        if (pend != kTravDone) {
+                            const int cnt = ((~pend) & 7) + 1;
+                            const int used = test_leaf(pend);
+                            pend = cnt > used ? pend - 7 * used : kTravDone;      // the leaf code moves on by `used` (first += used, count -= used)
+                            // done with it while standing on another leaf: that one is taken along now, and the lane moves on
+                            const bool stash = pend == kTravDone && cur < 0 && cur != kTravDone;
+                            pend = stash ? cur : pend;
+                            cur = stash ? top : cur;
+                            sp -= stash ? 1 : 0;
+                        }
+                    }
+                    const bool fin = was_busy && cur == kTravDone && pend == kTravDone;
+                    state = fin ? S_READY : state;
+                }
+                } else
                 for (;;) {
                     const unsigned long long in_mesh = wave_ballot(cur != kTravDone);
                     const int n = __popcll(in_mesh);
@@ -989,7 +1174,45 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     int new_cur = cur;                     // lanes of the other kind keep their position
                     if (2 * n_node >= n) {
                         PT_COUNT(cyc_trace, 1);
-                        if (cur >= 0) {
+                        if (kBvhWide && cur >= 0) {
+                            // four-wide node: the nearest child that is hit is visited next, the other hit children go on the
+                            // stack -- four unconditional stores, each kept (the height moves on) only if its child counts
+                            float4 mnx, mny, mnz, mxx, mxy, mxz;
+                            int c0, c1, c2, c3;
+                            st.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, c0, c1, c2, c3);
+                            const int top = (int)stk[(sp - 1) * kWave];
+                            n_bvh_nodes++;
+                            const float lim = fmaf(best_t, 1.001f, delta);
+                            float a0, a1;
+                            slab_test_fma(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, nlo, nhi, inv, a0, a1);
+                            const bool h0 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;      // slots 0 and 1 are always in use
+                            const float e0 = a0;
+                            slab_test_fma(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, nlo, nhi, inv, a0, a1);
+                            const bool h1 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;
+                            const float e1 = a0;
+                            slab_test_fma(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, nlo, nhi, inv, a0, a1);
+                            const bool h2 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c2 != kTravDone);
+                            const float e2 = a0;
+                            slab_test_fma(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, nlo, nhi, inv, a0, a1);
+                            const bool h3 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c3 != kTravDone);
+                            const float e3 = a0;
+                            // nearest hit child: a running minimum over the slots; b_k = slot k took the lead from the slots before it
+                            float et = h0 ? e0 : kInfinity * 4.0f;
+                            int ec = c0;
+                            const bool b1 = h1 && e1 < et; et = b1 ? e1 : et; ec = b1 ? c1 : ec;
+                            const bool b2 = h2 && e2 < et; et = b2 ? e2 : et; ec = b2 ? c2 : ec;
+                            const bool b3 = h3 && e3 < et; ec = b3 ? c3 : ec;
+                            const bool any = h0 | h1 | h2 | h3;
+                            // a hit child is pushed unless it ended up the nearest (slot k is the nearest iff b_k and no later b)
+                            const bool p0 = h0 & (b1 | b2 | b3), p1 = h1 & (!b1 | b2 | b3), p2 = h2 & (!b2 | b3), p3 = h3 & !b3;
+                            int s = sp;
+                            stk[s * kWave] = (unsigned)c0; s += p0 ? 1 : 0;
+                            stk[s * kWave] = (unsigned)c1; s += p1 ? 1 : 0;
+                            stk[s * kWave] = (unsigned)c2; s += p2 ? 1 : 0;
+                            stk[s * kWave] = (unsigned)c3; s += p3 ? 1 : 0;
+                            new_cur = any ? ec : top;
+                            sp = any ? s : sp - 1;
+                        } else if (cur >= 0) {
                             float4 a, b, c;
                             int kl, kr;
                             st.node(cur, a, b, c, kl, kr);
@@ -1011,43 +1234,9 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     } else {
                         PT_COUNT(cyc_shade, 1);
                         if (cur < 0 && cur != kTravDone) {
-                            const int code = ~cur, first = (code & (kSphereLeaf - 1)) >> 3, cnt = (code & 7) + 1;
+                            const int cnt = ((~cur) & 7) + 1;
                             const int top = (int)stk[(sp - 1) * kWave];
-                            int used;
-                            if (SPH && (code & kSphereLeaf) != 0) {
-                                // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
-                                float4 cr;
-                                int si;
-                                st.sphere(first, cr, si);
-                                float t; bool front;
-                                const bool has = hit_sphere(V(cr.x, cr.y, cr.z), cr.w, ps.o, ps.d, t, front, sc.sh.hit_limit, sh_xyz);
-                                const int id = sc.n_mesh + sc.n_tris + si;
-                                n_sph_tests++;
-                                const bool take = has & closer_hit(t, id, best_t, best_id);
-                                best_t = take ? t : best_t; best_id = take ? id : best_id;
-                                used = 1;
-                            } else {
-                                // up to two triangles of the leaf per step (independent tests: the second hides the first's latencies)
-                                const bool two = cnt >= 2;
-                                float4 p1, e1, e2, q1, f1, f2;
-                                st.tri(first, p1, e1, e2);
-                                st.tri(two ? first + 1 : first, q1, f1, f2);
-                                float t, det, t2, det2;
-                                bool bad = false;
-                                bool has = hit_triangle_t<true>(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, bad, sc.sh.hit_limit);
-                                bool has2 = hit_triangle_t<true>(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, bad, sc.sh.hit_limit);
-                                if (__builtin_expect(bad, 0)) {
-                                    has = hit_triangle_ieee(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), ps.o, ps.d, t, det, sc.sh.hit_limit);
-                                    has2 = hit_triangle_ieee(V(q1.x, q1.y, q1.z), V(f1.x, f1.y, f1.z), V(f2.x, f2.y, f2.z), ps.o, ps.d, t2, det2, sc.sh.hit_limit);
-                                }
-                                const int id = __float_as_int(p1.w), id2 = __float_as_int(q1.w);
-                                n_bvh_tests += two ? 2 : 1;
-                                const bool take = has & closer_hit(t, id, best_t, best_id);
-                                best_t = take ? t : best_t; best_id = take ? id : best_id;
-                                const bool take2 = (two & has2) & closer_hit(t2, id2, best_t, best_id);
-                                best_t = take2 ? t2 : best_t; best_id = take2 ? id2 : best_id;
-                                used = two ? 2 : 1;
-                            }
+                            const int used = test_leaf(cur);
                             // primitives left: the leaf code moves on by `used` (first += used, count -= used: ~code falls by
                             // 8 * used - used); none left: pop
                             const bool more_left = cnt > used;
@@ -1220,7 +1409,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         // the traversal starts from the hit among the primitives scanned one by one: the reference's in-order
                         // strict `<` scan returns the lexicographic minimum of (t, canonical id) over all of them, so the order
                         // of the candidates is free -- and subtrees beyond that hit are pruned from the first step
-                        sp = 1; best_t = s_t; best_id = s_id;
+                        sp = 1; best_t = s_t; best_id = s_id; pend = kTravDone;
                         cur = gate ? 0 : sph_root;
                         if (gate && sph_in) { stk[kWave] = (unsigned)sph_root; sp = 2; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins
@@ -1242,7 +1431,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
         for (int off = 32; off > 0; off >>= 1) { n_bvh_nodes += __shfl_xor(n_bvh_nodes, off); n_bvh_tests += __shfl_xor(n_bvh_tests, off); if (SPH) n_sph_tests += __shfl_xor(n_sph_tests, off); }
         if (lane == 0) {
             if (SPH) atomicAdd(&fp.counters[16], (unsigned long long)n_sph_tests);
-            atomicAdd(&fp.counters[17], 2ull * n_bvh_nodes);
+            atomicAdd(&fp.counters[17], (kBvhWide ? 4ull : 2ull) * n_bvh_nodes);
             atomicAdd(&fp.counters[0], (unsigned long long)n_samples);
             atomicAdd(&fp.counters[1], (unsigned long long)n_seg);
             atomicAdd(&fp.counters[2], (unsigned long long)n_mesh_seg);
@@ -1377,7 +1566,7 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
     st.shade = (lds_cf4v *)bvh_lds_small;
     st.scene = staged ? (lds_cf4v *)(bvh_lds_small + kShadeLdsVecs) : nullptr;
     st.stack = reinterpret_cast<unsigned *>(bvh_lds_small + kSceneLdsVecs) + wave * (stack_entries * kWave) + lane;
-    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
+    st.nodes = sc.bvh_nodes; st.nodes_q = sc.bvh_nodes_q; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
     trace_items_body_bvh<SPH, SHORT, GEN>(sc, fp, st, lane);
 }
 
@@ -1394,9 +1583,9 @@ __global__ void __launch_bounds__(BLOCK, 4) pt_trace_items_bvh_lds(SceneView sc,
     constexpr int kBvhLdsBlock = BLOCK;
     extern __shared__ float4 bvh_lds[];
     const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + 4 * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
+    float4 *nodes = bvh_lds, *tris = bvh_lds + kBvhNodeVecs * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
     unsigned *stack = reinterpret_cast<unsigned *>(scene + kSceneLdsVecs);
-    for (int i = threadIdx.x; i < 4 * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
+    for (int i = threadIdx.x; i < kBvhNodeVecs * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
     for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
     for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
     if (!GEN) { sc.sh.hit_limit = kHitLimit; sc.sh.box_slack = kBoxSlack; sc.sh.flags = kShDefault; }     // see trace_items_body_bvh
@@ -1489,7 +1678,7 @@ __global__ void __launch_bounds__(kWave) pt_primary_hits_bvh(SceneView sc, Frame
     __shared__ unsigned stack[kBvhStack * kWave];
     BvhStore st;
     st.stack = stack + threadIdx.x;
-    st.nodes = sc.bvh_nodes; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
+    st.nodes = sc.bvh_nodes; st.nodes_q = sc.bvh_nodes_q; st.tris = sc.bvh_tris; st.sph = sc.bvh_sph;
     primary_hits_body<SLOTS>(sc, fp, st, threadIdx.x, blockIdx.x);
 }
 
