@@ -207,7 +207,7 @@ inline void collapse_bvh4(const std::vector<BvhNode> &bin, Bvh4 &out, int base =
     struct Slot { Box b; int code; };
     struct Rec {
         const std::vector<BvhNode> &bin; Bvh4 &out; int base;
-        static void kids(const BvhNode &n, Slot &l, Slot &r)
+        void kids(const BvhNode &n, Slot &l, Slot &r) const
         {
             for (int k = 0; k < 3; k++) { l.b.mn[k] = n.lmin[k]; l.b.mx[k] = n.lmax[k]; r.b.mn[k] = n.rmin[k]; r.b.mx[k] = n.rmax[k]; }
             l.code = n.left; r.code = n.right;

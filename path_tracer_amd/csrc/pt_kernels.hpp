@@ -35,19 +35,6 @@ constexpr int kWave = 64;
 constexpr int kSlots = 11;                 // mesh triangles per lane held in registers
 constexpr int kNumCounters = 18;
 constexpr int kBvhStack = kBvhMaxDepth + 1;   // per-lane traversal stack entries (one extra: the sphere tree's root under the mesh tree)
-// PT_POSTPONE = 1: lanes carry one leaf along untested while they go on through the nodes (see the traversal phase of
-// trace_items_body_bvh); a node step is taken while n_node * DEN >= n_leaf * NUM (lanes that can visit a node vs lanes that
-// hold a leaf).  Needs the four-wide tree.
-#ifndef PT_POSTPONE
-#define PT_POSTPONE 1
-#endif
-#ifndef PT_POSTPONE_NUM
-#define PT_POSTPONE_NUM 1
-#endif
-#ifndef PT_POSTPONE_DEN
-#define PT_POSTPONE_DEN 1
-#endif
-constexpr bool kPostpone = PT_POSTPONE != 0 && kBvhWide;
 constexpr int kTravDone = (int)0x80000000;      // traversal position of a lane that is not traversing; the bottom of every stack; the code of an unused child slot
 constexpr int kChunk = kWave * kSlots;     // 704 triangles per register-resident chunk (bunny1: 656)
 
@@ -968,7 +955,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     int s_id = -1, best_id = -1;
     // resumable traversal state (see the traversal phase): position `cur`, stack height `sp` (slot 0 = kTravDone for good)
     int cur = kTravDone, sp = 1;
-    int pend = kTravDone;              // kPostpone: the leaf this lane carries along untested (a leaf code), kTravDone: none
     stk[0] = (unsigned)kTravDone;
     v3 inv = V(0, 0, 0);
     float delta = 0.0f;
@@ -1088,84 +1074,6 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     best_t = take2 ? t2 : best_t; best_id = take2 ? id2 : best_id;
                     return two ? 2 : 1;
                 };
-                if constexpr (kPostpone) {
-                // A lane that reaches a leaf does not stop for it: it takes the leaf along (`pend`) and goes on through the nodes
-                // until it stands on a second one.  Node steps then run for every lane that is not blocked on a second leaf, and
-                // a leaf step finds a leaf in (nearly) every lane -- instead of either kind of step idling the lanes that want the
-                // other (Aila & Laine's "speculative traversal", inside the wave's majority vote).  The hit a postponed leaf would
-                // have found cannot prune the nodes visited in between, so a few more nodes are visited; the set of primitives
-                // tested can only grow, and the result -- the lexicographic minimum of (t, id) -- is the same.
-                // Invariant between steps: cur >= 0 (a node to visit), or cur == kTravDone (nothing left on the stack), or cur is a
-                // leaf AND pend holds another (blocked until a leaf step).  Finished: cur == kTravDone and pend == kTravDone.
-                for (;;) {
-                    const unsigned long long m_node = wave_ballot(cur >= 0), m_leaf = wave_ballot(pend != kTravDone);
-                    const int n = __popcll(m_node | m_leaf);
-                    if (n <= exit_at) break;
-                    const int n_node = __popcll(m_node), n_leaf = __popcll(m_leaf);
-                    const bool was_busy = (cur >= 0) | (pend != kTravDone);
-                    // the top of the stack and the entry below it, read speculatively beside the step's own data (slot 0 holds
-                    // kTravDone for good; the indices are clamped for lanes that are not traversing, whose sp may be 0)
-                    const int top = (int)stk[max(sp - 1, 0) * kWave], below = (int)stk[max(sp - 2, 0) * kWave];
-                    if (n_node * PT_POSTPONE_DEN >= n_leaf * PT_POSTPONE_NUM) {
-                        PT_COUNT(cyc_trace, 1);
-                        if (cur >= 0) {
-                            float4 mnx, mny, mnz, mxx, mxy, mxz;
-                            int c0, c1, c2, c3;
-                            st.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, c0, c1, c2, c3);
-                            n_bvh_nodes++;
-                            const float lim = fmaf(best_t, 1.001f, delta);
-                            float a0, a1;
-                            slab_test_fma(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, nlo, nhi, inv, a0, a1);
-                            const bool h0 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;      // slots 0 and 1 are always in use
-                            const float e0 = a0;
-                            slab_test_fma(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, nlo, nhi, inv, a0, a1);
-                            const bool h1 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;
-                            const float e1 = a0;
-                            slab_test_fma(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, nlo, nhi, inv, a0, a1);
-                            const bool h2 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c2 != kTravDone);
-                            const float e2 = a0;
-                            slab_test_fma(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, nlo, nhi, inv, a0, a1);
-                            const bool h3 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c3 != kTravDone);
-                            const float e3 = a0;
-                            float et = h0 ? e0 : kInfinity * 4.0f;
-                            int ec = c0;
-                            const bool b1 = h1 && e1 < et; et = b1 ? e1 : et; ec = b1 ? c1 : ec;
-                            const bool b2 = h2 && e2 < et; et = b2 ? e2 : et; ec = b2 ? c2 : ec;
-                            const bool b3 = h3 && e3 < et; ec = b3 ? c3 : ec;
-                            const bool any = h0 | h1 | h2 | h3;
-                            const bool p0 = h0 & (b1 | b2 | b3), p1 = h1 & (!b1 | b2 | b3), p2 = h2 & (!b2 | b3), p3 = h3 & !b3;
-                            // the pushes, and in `tp` what is on top of the stack after them
-                            int s = sp, tp = top;
-                            stk[s * kWave] = (unsigned)c0; s += p0 ? 1 : 0; tp = p0 ? c0 : tp;
-                            stk[s * kWave] = (unsigned)c1; s += p1 ? 1 : 0; tp = p1 ? c1 : tp;
-                            stk[s * kWave] = (unsigned)c2; s += p2 ? 1 : 0; tp = p2 ? c2 : tp;
-                            stk[s * kWave] = (unsigned)c3; s += p3 ? 1 : 0; tp = p3 ? c3 : tp;
-                            const int next = any ? ec : top;             // no child hit: pop
-                            const int next_top = any ? tp : below;
-                            const int next_sp = any ? s : sp - 1;
-                            // the new position is a leaf and none is pending: take it along and pop
-                            const bool stash = next < 0 && next != kTravDone && pend == kTravDone;
-                            pend = stash ? next : pend;
-                            cur = stash ? next_top : next;
-                            sp = stash ? next_sp - 1 : next_sp;
-                        }
-                    } else {
-                        PT_COUNT(cyc_shade, 1);
-                        if (pend != kTravDone) {
-                            const int cnt = ((~pend) & 7) + 1;
-                            const int used = test_leaf(pend);
-                            pend = cnt > used ? pend - 7 * used : kTravDone;      // the leaf code moves on by `used` (first += used, count -= used)
-                            // done with it while standing on another leaf: that one is taken along now, and the lane moves on
-                            const bool stash = pend == kTravDone && cur < 0 && cur != kTravDone;
-                            pend = stash ? cur : pend;
-                            cur = stash ? top : cur;
-                            sp -= stash ? 1 : 0;
-                        }
-                    }
-                    const bool fin = was_busy && cur == kTravDone && pend == kTravDone;
-                    state = fin ? S_READY : state;
-                }
-                } else
                 for (;;) {
                     const unsigned long long in_mesh = wave_ballot(cur != kTravDone);
                     const int n = __popcll(in_mesh);
@@ -1409,7 +1317,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         // the traversal starts from the hit among the primitives scanned one by one: the reference's in-order
                         // strict `<` scan returns the lexicographic minimum of (t, canonical id) over all of them, so the order
                         // of the candidates is free -- and subtrees beyond that hit are pruned from the first step
-                        sp = 1; best_t = s_t; best_id = s_id; pend = kTravDone;
+                        sp = 1; best_t = s_t; best_id = s_id;
                         cur = gate ? 0 : sph_root;
                         if (gate && sph_in) { stk[kWave] = (unsigned)sph_root; sp = 2; }
                         // the slab tests only steer the traversal: v_rcp_f32 (1 ulp) is far inside their margins

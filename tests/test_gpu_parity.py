@@ -542,12 +542,22 @@ def test_one_shared_lds_copy_per_cu_for_trees_that_do_not_fit_twice(capi, camera
     assert r.kernel_name().startswith("pt_trace_items_bvh_lds<") and r.kernel_name().endswith(", 1024>"), r.kernel_name()
     assert n_diff_pixels(r.read_accum()[:, :, :3], g["mixed_b16_128x72_mean16"]) == 0
     r.close()
+    # a mesh small enough for either shape (200 triangles): both forced, the images must agree bit for bit
+    from path_tracer_amd import scene as S
+    sc, cam = S.default_scene(S.heightfield_mesh(10, 3)), S.heightfield_camera()
     imgs = {}
     for block in (512, 1024):
-        r = make(capi, scenes["default"], cameras["bench"], 640, 360, 8)
+        r = make(capi, sc, cam, 640, 360, 8)
         r.set_option("lds_block", block)
         r.render(1, 6)
         assert r.kernel_name().endswith(f", {block}>"), r.kernel_name()
         imgs[block] = r.read_accum()
         r.close()
     assert bits_equal(imgs[512], imgs[1024])
+    # a forced shape the trees do not fit falls back to the kernel that reads them in place (variant 5), same image
+    r = make(capi, scenes["mixed"], cameras["mixed"], 128, 72, 16)
+    r.set_option("lds_block", 512)
+    r.render(1, 16)
+    assert r.kernel_name().startswith("pt_trace_items_bvh<true"), r.kernel_name()
+    assert n_diff_pixels(r.read_accum()[:, :, :3], g["mixed_b16_128x72_mean16"]) == 0
+    r.close()
