@@ -140,7 +140,7 @@ def profiled_traffic(kernel_name, config):
             if d.get("kernel", "").split("<")[0] != kernel_name.split("<")[0]:
                 break
             dv = d["derived"]
-            rd = next(v for k, v in dv.items() if k.startswith("hbm_read_bytes_per_launch"))
+            rd = dv["hbm_read_bytes_per_launch"] if "hbm_read_bytes_per_launch" in dv else next(v for k, v in dv.items() if k.startswith("hbm_read_bytes_per_launch"))
             wr = next(v for k, v in dv.items() if k.startswith("hbm_write_bytes_per_launch"))
             return {"traffic": rd + wr, "traffic_unit": "bytes per launch (read %.3g + write %.3g)" % (rd, wr),
                     "traffic_source": os.path.relpath(path, ROOT)}

@@ -317,7 +317,7 @@ constexpr int kBvhStackExtra = 3;
 constexpr size_t kBvhLdsLimit = 80 * 1024, kBvhLdsLimitWide = 158 * 1024;
 size_t bvh_lds_bytes(const pt_ctx *c, int block)
 {
-    return (size_t)c->bvh_n_nodes * (kBvhNodeVecs * 16) + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
+    return (size_t)c->bvh_n_nodes * (kBvhLdsNodeVecs * 16) + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
            + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * (size_t)block;
 }
 // The LDS-resident traversal kernels take more dynamic LDS than a kernel may by default: the cap is lifted for every
@@ -430,7 +430,7 @@ int sync_bvh(pt_ctx *c)
         } else {
             HIPCHK(c, c->bvh_nodes.upload(data, bytes, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            c->bvh_depth = std::max(need_mesh, need_sph) + 1;   // + the other tree's root on the stack
+            c->bvh_depth = std::max(need_mesh, need_sph) + ((mesh && sph) ? 1 : 0);   // + the other tree's root on the stack, where there are two
             c->bvh_scale = std::max(mesh ? c->mesh_scale : 0.0f, sph ? c->sph_scale : 0.0f);
         }
     }

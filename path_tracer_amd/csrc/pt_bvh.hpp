@@ -1,4 +1,4 @@
-// pt_bvh.hpp — host-side BVH builder for the mesh triangles (binned SAH, BVH2, leaves of <= kLeafMax triangles).
+// pt_bvh.hpp — host-side BVH builder for the mesh triangles (binned SAH, BVH2, leaves of <= kLeafMax triangles, collapsed to a four-wide tree).
 //
 // The reference has no working acceleration structure: its shader tests every mesh triangle behind a root-AABB gate
 // (rt.comp:213-218; `TraverseBVH`, rt.comp:182-202, is dead code and `Mesh::SplitNode`, src/Object.cpp:183-240, is
@@ -90,6 +90,7 @@ struct Builder {
     std::vector<Ref> refs;
     Bvh *out;
     int leaf_flag = 0;
+    int leaf_max = kLeafMax;          // primitives per leaf the builder aims for
 
     static int ceil_log2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
@@ -109,14 +110,14 @@ struct Builder {
     {
         const int n = hi - lo;
         out->depth = std::max(out->depth, depth);
-        if (n <= kLeafMax) return make_leaf(lo, hi);
+        if (n <= leaf_max) return make_leaf(lo, hi);
         Box cb; cb.reset();
         for (int i = lo; i < hi; i++) cb.grow(refs[i].c);
         int axis = 0;
         for (int k = 1; k < 3; k++) if (cb.mx[k] - cb.mn[k] > cb.mx[axis] - cb.mn[axis]) axis = k;
         int mid = -1;
         // SAH only while a median-split subtree below still fits in the depth bound
-        const bool may_sah = depth + 1 + ceil_log2((n + kLeafMax - 1) / kLeafMax) + 1 < kBvhMaxDepth;
+        const bool may_sah = depth + 1 + ceil_log2((n + leaf_max - 1) / leaf_max) + 1 < kBvhMaxDepth;
         if (may_sah && cb.mx[axis] > cb.mn[axis]) {
             constexpr int kBins = 16;
             float best_cost = INFINITY; int best_axis = -1, best_bin = -1;
@@ -180,7 +181,7 @@ inline void build_from_refs(bvh_detail::Builder &b, Bvh &out)
     b.out = &out;
     out.order.reserve(n);
     out.nodes.reserve(std::max(1, n / 2));
-    if (n <= kLeafMax) {
+    if (n <= b.leaf_max) {
         // the traversal starts at an inner node: root = (leaf of everything, the same leaf again)
         out.nodes.emplace_back();
         const Box lb = b.bounds(0, n);
@@ -299,7 +300,7 @@ inline void build_bvh(const PtTriangle *tris, int n, Bvh &out)
 inline void build_sphere_bvh(const PtSphere *sph, int n, Bvh &out)
 {
     using namespace bvh_detail;
-    Builder b; b.refs.resize(std::max(0, n)); b.leaf_flag = kSphereLeaf;
+    Builder b; b.refs.resize(std::max(0, n)); b.leaf_flag = kSphereLeaf; b.leaf_max = kSphLeafMax;
     for (int i = 0; i < n; i++) {
         Ref &r = b.refs[i];
         const float rad = std::fabs(sph[i].radius);

@@ -401,7 +401,7 @@ struct BvhLdsStore {
     static constexpr bool kChildTest = false;
     __device__ __forceinline__ void node4(int i, float4 &mnx, float4 &mny, float4 &mnz, float4 &mxx, float4 &mxy, float4 &mxz, int &c0, int &c1, int &c2, int &c3) const
     {
-        lds_cf4v *n = nodes + 8 * i;
+        lds_cf4v *n = nodes + kBvhLdsNodeVecs * i;
         mnx = f4(n[0]); mny = f4(n[1]); mnz = f4(n[2]); mxx = f4(n[3]); mxy = f4(n[4]); mxz = f4(n[5]);
         const f4v k = n[6];
         c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
@@ -1042,7 +1042,9 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 auto test_leaf = [&](int code_neg) -> int {
                     const int code = ~code_neg, first = (code & (kSphereLeaf - 1)) >> 3, cnt = (code & 7) + 1;
                     if (SPH && (code & kSphereLeaf) != 0) {
-                        // one sphere of a sphere-tree leaf (rt.comp:126-146), canonical id after the mesh and scene triangles
+                        // one sphere of a sphere-tree leaf per step (rt.comp:126-146), canonical id after the mesh and scene
+                        // triangles.  Two per step, like the triangles, was measured and is slower (config 5: 36.5 vs 35.1 ms): the
+                        // test is dear (a square root and two divisions) and in a leaf of one or three the second is wasted
                         float4 cr;
                         int si;
                         st.sphere(first, cr, si);
@@ -1147,7 +1149,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                             const int used = test_leaf(cur);
                             // primitives left: the leaf code moves on by `used` (first += used, count -= used: ~code falls by
                             // 8 * used - used); none left: pop
-                            const bool more_left = cnt > used;
+                            const bool more_left = !kOneStepLeaves && cnt > used;
                             new_cur = more_left ? cur - 7 * used : top;
                             sp -= more_left ? 0 : 1;
                         }
@@ -1479,7 +1481,7 @@ __global__ void __launch_bounds__(kLdsBlock, 4) pt_trace_items_bvh(SceneView sc,
 }
 
 // The same with the whole BVH staged into LDS once per workgroup: persistent 8-wave workgroups, two per CU; dynamic
-// LDS = nodes (64 B each) | triangles (48 B each) | spheres (32 B each) | wave-uniform operands (kSceneLdsVecs x 16 B) | stacks
+// LDS = nodes (112 B each: pt_bvh_format.hpp kBvhLdsNodeVecs) | triangles (48 B each) | spheres (32 B each) | wave-uniform operands (kSceneLdsVecs x 16 B) | stacks
 // (stack_entries x 4 B x 512 lanes).
 // BLOCK = 512: two workgroups per CU, each with its own copy (trees + stacks up to 80 KB); BLOCK = 1024: ONE workgroup per
 // CU whose sixteen waves share one copy, for trees that do not fit twice (up to 160 KB with the stacks) -- the same four
@@ -1491,9 +1493,9 @@ __global__ void __launch_bounds__(BLOCK, 4) pt_trace_items_bvh_lds(SceneView sc,
     constexpr int kBvhLdsBlock = BLOCK;
     extern __shared__ float4 bvh_lds[];
     const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + kBvhNodeVecs * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
+    float4 *nodes = bvh_lds, *tris = bvh_lds + kBvhLdsNodeVecs * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
     unsigned *stack = reinterpret_cast<unsigned *>(scene + kSceneLdsVecs);
-    for (int i = threadIdx.x; i < kBvhNodeVecs * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[i];
+    for (int i = threadIdx.x; i < kBvhLdsNodeVecs * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[(i / kBvhLdsNodeVecs) * kBvhNodeVecs + i % kBvhLdsNodeVecs];
     for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
     for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
     if (!GEN) { sc.sh.hit_limit = kHitLimit; sc.sh.box_slack = kBoxSlack; sc.sh.flags = kShDefault; }     // see trace_items_body_bvh
