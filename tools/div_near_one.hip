@@ -22,7 +22,7 @@ __global__ void check(unsigned long long *bad, uint32_t a_bits)
     for (uint32_t j = 0; j < 256; j++) {
         const float x = __uint_as_float(base | j);
         const float ref = x / a;
-        // the kernel's acceptance rule (pt_math.hpp div2_near_one): the numerator is at least 2^-100 in magnitude (below that
+        // the acceptance rule a kernel would apply: the numerator is at least 2^-100 in magnitude (below that
         // the residual x - a * q0, ~2^-24 |x|, falls under the denormal range and corrects nothing) and the SHORT form's own
         // result is a normal number (an overflowing x * r turns it into NaN, which the rule rejects); everything else takes
         // the IEEE divide
