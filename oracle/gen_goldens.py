@@ -202,6 +202,28 @@ def main():
         meta["entries"]["radiance_mixed_b16_640x360"] = {"crc_mean1": crc(img[0, :, :, :3]), "crc_mean4": crc(img[3, :, :, :3]), "llvmpipe_timing": tm}
         print("radiance c1", e)
 
+    # ---- 3c. other meshes of the reference's res/meshes, rendered by the reference's rt.comp itself --------
+    # dragon1 (5,438 triangles: eight register chunks for the brute-force kernel; too large for LDS, so the traversal kernel
+    # reads its quantised tree in place) in main()'s scene, and suzanne (967 triangles: two chunks; tree in LDS) in the mixed
+    # scene.  The parsed arrays travel as data (tests/golden/mesh_*.npz); the images are the reference's.
+    if want("meshes"):
+        arrs = {}
+        for name, mat, mixed, cam, b in (("dragon1", 3, False, bench_cam, 8), ("suzanne", 1, True, mixed_cam, 16)):
+            v, fidx = S.load_obj(os.path.join(ref, "res", "meshes", name + ".obj"))
+            np.savez_compressed(os.path.join(GOLD, f"mesh_{name}.npz"), vertices=v, faces=fidx)
+            mesh = S.Mesh.from_arrays(v, fidx, mat)
+            sc = S.mixed_scene(mesh) if mixed else S.default_scene(mesh)
+            img, _ = run_reference(ref, sc, cam, 128, 72, 8, b, every=True)
+            for k in (1, 2, 4, 8):
+                arrs[f"{name}_b{b}_128x72_mean{k}"] = img[k - 1, :, :, :3].copy()
+            ids_img, _ = run_reference(ref, sc, cam, 128, 72, 1, 3, first_pass=1, dump=1)
+            arrs[f"{name}_128x72_p1_ids"] = ids_img[0, :, :, 0].astype(np.int16)
+            img, _ = run_reference(ref, sc, cam, 640, 360, 2, b, every=True)
+            meta["entries"][f"radiance_{name}_b{b}_640x360"] = {"crc_mean1": crc(img[0, :, :, :3]), "crc_mean2": crc(img[1, :, :, :3]),
+                                                                 "n_primary_hits_128x72": int((arrs[f"{name}_128x72_p1_ids"] >= 0).sum())}
+            print("mesh", name, v.shape, fidx.shape, meta["entries"][f"radiance_{name}_b{b}_640x360"])
+        np.savez_compressed(os.path.join(GOLD, "radiance_meshes_128x72.npz"), **arrs)
+
     # ---- 3a. the legacy rt.frag constant set: rt.frag itself, 12 bounces as shipped and 4 -----
     if want("frag"):
         arrs = {}

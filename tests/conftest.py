@@ -57,3 +57,19 @@ def scenes():
 
 
 SCENE_CAM = {"default": ("default", "bench"), "default_rot": ("default", "rot"), "mixed": ("mixed", "mixed")}
+
+
+MESH_CASES = {"dragon1": dict(material=3, mixed=False, cam="bench", bounces=8), "suzanne": dict(material=1, mixed=True, cam="mixed", bounces=16)}
+
+
+@pytest.fixture(scope="session")
+def mesh_scenes():
+    """other meshes of the reference's res/meshes (parsed arrays in tests/golden/mesh_*.npz: data) in main()'s scene / the mixed
+    scene, as oracle/gen_goldens.py rendered them with the reference's rt.comp (radiance_meshes_128x72.npz)"""
+    from path_tracer_amd import scene as S
+    out = {}
+    for name, c in MESH_CASES.items():
+        z = np.load(os.path.join(GOLD, f"mesh_{name}.npz"))
+        mesh = S.Mesh.from_arrays(z["vertices"], z["faces"], c["material"])
+        out[name] = S.mixed_scene(mesh) if c["mixed"] else S.default_scene(mesh)
+    return out

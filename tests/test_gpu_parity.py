@@ -357,6 +357,40 @@ def test_config3_at_baseline_size_64spp_8_bounces(capi):
         assert n_diff_pixels(full[y0:y0 + h, x0:x0 + w], want) == 0, (x0, y0)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 5, 6])
+@pytest.mark.parametrize("name", ["dragon1", "suzanne"])
+def test_other_reference_meshes_vs_reference_fixtures(capi, name, variant, meta, cameras, mesh_scenes):
+    """two more meshes of the reference's res/meshes against the reference's own shader under llvmpipe: dragon1 (5,438 triangles:
+    eight register chunks for the brute-force kernel, a tree too large for LDS -> the quantised four-wide nodes read in place)
+    and suzanne in the mixed scene (967 triangles + 145 spheres, trees in LDS); default kernel, brute force, both traversal
+    kernels; running means after passes 1, 2, 4, 8 at 128x72, primary-hit ids, and the 640x360 CRC"""
+    from conftest import MESH_CASES
+    c = MESH_CASES[name]
+    sc, cam, b = mesh_scenes[name], cameras[c["cam"]], c["bounces"]
+    g = np.load(os.path.join(GOLD, "radiance_meshes_128x72.npz"))
+    r = make(capi, sc, cam, 128, 72, b)
+    if variant:
+        r.set_tuning(0, 0, 0, variant)
+    first = 1
+    for k in (1, 2, 4, 8):
+        r.render(first, k - first + 1)
+        first = k + 1
+        assert n_diff_pixels(r.read_accum()[:, :, :3], g[f"{name}_b{b}_128x72_mean{k}"]) == 0, f"running mean after pass {k}"
+    want = {0: "pt_trace_items_bvh", 1: "pt_trace_items<", 5: "pt_trace_items_bvh<", 6: "pt_trace_items_bvh"}[variant]
+    assert r.kernel_name().startswith(want), r.kernel_name()
+    if name == "dragon1" and variant in (0, 6):
+        assert r.kernel_name().startswith("pt_trace_items_bvh<"), "5,438 triangles do not fit in LDS: the tree is read in place"
+    ids = r.read_primary_hits(1)[0]
+    assert np.array_equal(ids.astype(np.int16), g[f"{name}_128x72_p1_ids"])
+    r.close()
+    r = make(capi, sc, cam, 640, 360, b)
+    if variant:
+        r.set_tuning(0, 0, 0, variant)
+    r.render(1, 2)
+    assert crc(r.read_accum()[:, :, :3]) == meta[f"radiance_{name}_b{b}_640x360"]["crc_mean2"]
+    r.close()
+
+
 def test_config5_at_baseline_size_64spp_16_bounces(capi, cameras, scenes):
     """BASELINE.json configs[4] on one GPU at its full size -- the mixed scene (bunny1 diffuse + specular, the 12 x 12 grid of
     glass spheres and the large sphere of src/Main.cpp:76-92, emissive and ground triangles), 1920x1080, 64 spp, 16 bounces --

@@ -91,6 +91,27 @@ def test_running_mean_radiance_bit_exact(tag, bounces, cameras, scenes):
     assert np.all(acc[:, :, 3] == 1.0)
 
 
+@pytest.mark.parametrize("name", ["dragon1", "suzanne"])
+def test_other_reference_meshes_bit_exact(name, meta, cameras, mesh_scenes):
+    """dragon1 (5,438 triangles) in main()'s scene at 8 bounces, suzanne (967) in the mixed scene at 16: running means after
+    passes 1, 2, 4, 8 and the primary-hit ids at 128x72, and the 640x360 CRCs, against the reference's rt.comp under llvmpipe"""
+    from conftest import MESH_CASES
+    c = MESH_CASES[name]
+    sc, cam, b = mesh_scenes[name], cameras[c["cam"]], c["bounces"]
+    g = np.load(os.path.join(GOLD, "radiance_meshes_128x72.npz"))
+    o = O.Oracle(sc, cam, 128, 72, b)
+    acc = np.zeros((72, 128, 4), np.float32)
+    for k in range(1, 9):
+        o.render(k, 1, acc)
+        if k in (1, 2, 4, 8):
+            assert n_diff_pixels(acc[:, :, :3], g[f"{name}_b{b}_128x72_mean{k}"]) == 0, f"running mean after pass {k}"
+    ids = o.primary_hits(1)[0]
+    assert np.array_equal(ids.astype(np.int16), g[f"{name}_128x72_p1_ids"])
+    assert (ids >= 0).sum() == meta[f"radiance_{name}_b{b}_640x360"]["n_primary_hits_128x72"] and (ids < len(sc.mesh_tris)).any()
+    acc = O.Oracle(sc, cam, 640, 360, b).render(1, 2)
+    assert crc(acc[:, :, :3]) == meta[f"radiance_{name}_b{b}_640x360"]["crc_mean2"]
+
+
 def test_config1_640x360_16spp_4bounces(meta, cameras, scenes):
     """BASELINE.json configs[0] exactly, against the reference run."""
     acc = O.Oracle(scenes["default"], cameras["bench"], 640, 360, 4).render(1, 16)
