@@ -1369,6 +1369,25 @@ int pt_bvh_selftest(const PtTriangle *tris, int n, int *n_nodes, int *depth, int
         w4k.walk(0, 0, 0);
         for (int i = 0; i < n; i++) if (seen4[i] != expect) ok4 = false;
         if (!ok4 || w4k.max_push != w4.stack_need) return PT_E_STATE;
+        // the 64-byte quantised form (read in place by the global-memory kernel): every plane a lane rebuilds,
+        // fmaf(q, 2^e, o), must lie on or outside the float plane it stands for, and the codes must be the float node's
+        for (const BvhNode4 &nd : w4.nodes) {
+            BvhNode4Q q;
+            if (!quantise_bvh4(nd, q)) return PT_E_STATE;
+            const float *mn[3] = {nd.mnx, nd.mny, nd.mnz}, *mx[3] = {nd.mxx, nd.mxy, nd.mxz};
+            for (int k = 0; k < 3; k++) {
+                const uint32_t eb = (q.exps >> (8 * k)) & 0xffu;
+                float step; const uint32_t sb = eb << 23; std::memcpy(&step, &sb, 4);
+                for (int i = 0; i < 4; i++) {
+                    if (q.child[i] != nd.child[i]) return PT_E_STATE;
+                    if (nd.child[i] == kBvhNoChild) continue;
+                    const float lo = std::fmaf((float)q.qmn[k][i], step, q.o[k]), hi = std::fmaf((float)q.qmx[k][i], step, q.o[k]);
+                    if (!(lo <= mn[k][i] && hi >= mx[k][i])) return PT_E_STATE;
+                    // ... and not by more than two steps (the quantisation must stay tight enough to cull)
+                    if (!(mn[k][i] - lo <= 2.0f * step && hi - mx[k][i] <= 2.0f * step)) return PT_E_STATE;
+                }
+            }
+        }
     }
     if (n_nodes) *n_nodes = (int)bvh.nodes.size();
     if (depth) *depth = bvh.depth;
