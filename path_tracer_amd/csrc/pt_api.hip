@@ -834,12 +834,14 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
     if (n > 0 && finite && scale < 1e18f) {
         build_bvh(tris, n, bvh);
         if (bvh.depth <= kBvhMaxDepth && (int)bvh.order.size() == n) {
-            btris.resize((size_t)3 * n);
+            btris.resize((size_t)kBvhTriVecs * n);
             for (int j = 0; j < n; j++) {
                 const int i = bvh.order[j];
                 float idf; std::memcpy(&idf, &i, 4);
-                btris[3 * (size_t)j] = make_float4(p1[i].x, p1[i].y, p1[i].z, idf);
-                btris[3 * (size_t)j + 1] = e1[i]; btris[3 * (size_t)j + 2] = e2[i];
+                float4 *r = &btris[kBvhTriVecs * (size_t)j];
+                r[0] = make_float4(p1[i].x, p1[i].y, p1[i].z, idf);
+                r[1] = make_float4(e1[i].x, e1[i].y, e1[i].z, p1[i].w);      // | material (the canonical record keeps it in p1.w)
+                r[2] = e2[i]; r[3] = nr[i];
             }
             HIPCHK(c, c->bvh_tris.upload(btris.data(), btris.size() * sizeof(float4), c->stream));
             c->h_mesh_nodes.swap(bvh.nodes);

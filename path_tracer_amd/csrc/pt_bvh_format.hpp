@@ -27,6 +27,7 @@ constexpr int kBvhNodeVecs = kBvhWide ? 8 : 4;    // float4 per inner node in gl
 // node stride from 32 banks to 28 (112 B): node starts then fall on 16 different banks instead of 2, which matters for a
 // gather in which every lane reads its own node
 constexpr int kBvhLdsNodeVecs = kBvhWide ? 7 : 4;
+constexpr int kBvhTriVecs = 4;                    // float4 per leaf-ordered triangle record in global memory: p1|index, e1|material, e2, normal
 constexpr float kBvhFarBox = 3.0e38f;             // both corners of an unused child slot: no ray's slab test reaches it (see pt_bvh.hpp)
 constexpr int kSphereLeaf = 1 << 30; // leaf-code flag: the leaf holds spheres (records of the sphere tree), not mesh triangles
 }  // namespace pt

@@ -80,7 +80,7 @@ struct SceneView {
     // BVH over the mesh triangles (pt_bvh.hpp), used by the traversal variant
     const float4 *bvh_nodes;  // kBvhNodeVecs x float4 per inner node: child boxes + child codes (pt_bvh.hpp BvhNode4 / BvhNode); staged into LDS by variant 6
     const float4 *bvh_nodes_q; // the four-wide nodes in their 64-byte quantised form (BvhNode4Q), read in place by variant 5
-    const float4 *bvh_tris;   // 3 x float4 per triangle in leaf order: (p1, bits(original index)), e1, e2
+    const float4 *bvh_tris;   // kBvhTriVecs x float4 per triangle in leaf order: (p1, bits(original index)), (e1, material), e2, normal
     float bvh_scale;          // largest |coordinate| of the mesh and the spheres (for the traversal's safety margin)
     const float4 *bvh_sph;    // sphere tree leaves, 2 x float4 per sphere in leaf order: (centre, radius), (bits(sphere index), -, -, -)
     float sph_bmin[3], sph_bmax[3];   // bounds of all spheres (centre -+ |radius|); read once per workgroup (stage_scene_lds)
@@ -371,9 +371,13 @@ struct BvhStore {
         mxx = PT_DEQ(__float_as_uint(qa.w), sx, o.x); mxy = PT_DEQ(__float_as_uint(qb.x), sy, o.y); mxz = PT_DEQ(__float_as_uint(qb.y), sz, o.z);
 #undef PT_DEQ
     }
+    // leaf-ordered triangle records, 64 B each (one cache line): (p1 | canonical index), (e1 | material), (e2 | 0), (normal | 0).
+    // The traversal reads the first three; the resolve phase reads the record of the winning triangle again -- the line the
+    // leaf step has just brought in -- instead of a fourth, cold line of the canonical table (kLeafRecords)
+    static constexpr bool kLeafRecords = true;
     __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
     {
-        const float4 *t = tris + 3 * (size_t)j;
+        const float4 *t = tris + kBvhTriVecs * (size_t)j;
         p1 = t[0]; e1 = t[1]; e2 = t[2];
     }
     const float4 *sph;
@@ -406,6 +410,8 @@ struct BvhLdsStore {
         const f4v k = n[6];
         c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
     }
+    // the LDS copy keeps the first three vectors of each record; the resolve phase goes to the canonical table
+    static constexpr bool kLeafRecords = false;
     __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
     {
         lds_cf4v *t = tris + 3 * j;
@@ -604,7 +610,8 @@ __device__ __forceinline__ void scene_closest_tab(const SceneView &sc, v3 o, v3 
         if (has && t < best_t) { best_t = t; best_id = sc.n_mesh + sc.n_tris + i; }
     }
 }
-__device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, Hit &h, bool xyz)
+// leaf_rec >= 0: the hit is mesh triangle h.id and its leaf-ordered record (BvhStore::kLeafRecords) is sc.bvh_tris[leaf_rec]
+__device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, Hit &h, bool xyz, int leaf_rec = -1)
 {
     if (h.id < 0) return;
     if (h.id >= sc.n_mesh + sc.n_tris) {
@@ -618,14 +625,15 @@ __device__ __forceinline__ void finish_hit_tab(const SceneView &sc, v3 o, v3 d, 
         h.normal = front ? n : -n;                                      // rt.comp:147
         h.mat = sc.sph_mat[i];
     } else {
-        const float4 *r = sc.prim_tab + 4 * (size_t)h.id;
+        const bool leaf = leaf_rec >= 0;
+        const float4 *r = leaf ? sc.bvh_tris + kBvhTriVecs * (size_t)leaf_rec : sc.prim_tab + 4 * (size_t)h.id;
         const float4 p1 = r[0], e1 = r[1], e2 = r[2], nr = r[3];
         float t, det;
         hit_triangle(V(p1.x, p1.y, p1.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), o, d, t, det, sc.sh.hit_limit);
         v3 n = V(nr.x, nr.y, nr.z);
         h.front = !(det < 0.0f);                                        // rt.comp:174
         h.normal = det < 0.0f ? n : -n;                                 // rt.comp:177
-        h.mat = __float_as_uint(p1.w);
+        h.mat = __float_as_uint(leaf ? e1.w : p1.w);
     }
 }
 
@@ -953,6 +961,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     // closest hit: scene primitives (s_t, s_id); mesh traversal / final result (best_t, best_id)
     float s_t = kInfinity, best_t = kInfinity;
     int s_id = -1, best_id = -1;
+    int best_rec = 0;                 // leaf-order index of mesh triangle best_id (Store::kLeafRecords)
     // resumable traversal state (see the traversal phase): position `cur`, stack height `sp` (slot 0 = kTravDone for good)
     int cur = kTravDone, sp = 1;
     stk[0] = (unsigned)kTravDone;
@@ -1074,6 +1083,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                     best_t = take ? t : best_t; best_id = take ? id : best_id;
                     const bool take2 = (two & has2) & closer_hit(t2, id2, best_t, best_id);
                     best_t = take2 ? t2 : best_t; best_id = take2 ? id2 : best_id;
+                    if constexpr (Store::kLeafRecords) { best_rec = take ? first : best_rec; best_rec = take2 ? first + 1 : best_rec; }
                     return two ? 2 : 1;
                 };
                 for (;;) {
@@ -1169,7 +1179,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 if (state == S_READY) {
                     Hit h;
                     h.id = best_id; h.t = best_t; h.front = false; h.normal = V(0, 0, 0); h.mat = 0;
-                    finish_hit_tab(sc, ps.o, ps.d, h, sh_xyz);
+                    finish_hit_tab(sc, ps.o, ps.d, h, sh_xyz, (Store::kLeafRecords && best_id >= 0 && best_id < sc.n_mesh) ? best_rec : -1);
                     const bool hit = h.id >= 0 && h.t < kInfinity;
                     bool done = true;
                     v3 colour;
@@ -1496,7 +1506,7 @@ __global__ void __launch_bounds__(BLOCK, 4) pt_trace_items_bvh_lds(SceneView sc,
     float4 *nodes = bvh_lds, *tris = bvh_lds + kBvhLdsNodeVecs * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
     unsigned *stack = reinterpret_cast<unsigned *>(scene + kSceneLdsVecs);
     for (int i = threadIdx.x; i < kBvhLdsNodeVecs * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[(i / kBvhLdsNodeVecs) * kBvhNodeVecs + i % kBvhLdsNodeVecs];
-    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i];
+    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i + i / 3];      // 3 of the 4 vectors of a record
     for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
     if (!GEN) { sc.sh.hit_limit = kHitLimit; sc.sh.box_slack = kBoxSlack; sc.sh.flags = kShDefault; }     // see trace_items_body_bvh
     const bool staged = stage_scene_lds(scene, sc, fp, threadIdx.x, kBvhLdsBlock);
