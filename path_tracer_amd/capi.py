@@ -23,7 +23,7 @@ SYMBOLS = [
     "pt_upload_scene", "pt_set_camera", "pt_set_debug_normal", "pt_set_max_bounces", "pt_render_pass", "pt_render", "pt_render_static",
     "pt_render_sum", "pt_scale_accum", "pt_reset", "pt_synchronize", "pt_read_accum", "pt_accum_device_ptr",
     "pt_read_primary_hits", "pt_get_counters", "pt_reset_counters", "pt_last_render_ms", "pt_set_tuning", "pt_set_option",
-    "pt_shading_preset", "pt_set_shading_params", "pt_get_shading_params", "pt_bvh_selftest", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
+    "pt_shading_preset", "pt_set_shading_params", "pt_get_shading_params", "pt_bvh_selftest", "pt_classify_mesh", "pt_group_unique_id", "pt_group_init", "pt_group_render", "pt_group_finalize",
     "pt_kernel_name", "pt_last_kernel_name",
     "pt_version",
 ]
@@ -133,6 +133,7 @@ def load():
     L.pt_set_shading_params.argtypes = [vp, C.POINTER(PtShadingParams)]
     L.pt_get_shading_params.argtypes = [vp, C.POINTER(PtShadingParams)]
     L.pt_bvh_selftest.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
+    L.pt_classify_mesh.argtypes = [vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
     L.pt_group_unique_id.argtypes = [C.c_char_p]
     L.pt_group_init.argtypes = [vp, C.c_char_p, i32, i32]
     L.pt_group_render.argtypes = [vp, i32, i32]
@@ -296,6 +297,15 @@ class Renderer:
         p = PtShadingParams()
         self._ck(self.L.pt_get_shading_params(self.h, C.byref(p)))
         return p
+
+
+def classify_mesh(tris):
+    """Host-only: how pt_upload_mesh sorts the triangles (pt_classify_mesh); returns (rc, in_tree, listed, never, max_growth)."""
+    L = load()
+    t = np.ascontiguousarray(tris)
+    a, b, c, f = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+    rc = L.pt_classify_mesh(t.ctypes.data, len(t), C.byref(a), C.byref(b), C.byref(c), C.byref(f))
+    return rc, a.value, b.value, c.value, f.value
 
 
 def bvh_selftest(tris):

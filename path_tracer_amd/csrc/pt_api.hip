@@ -131,6 +131,8 @@ struct pt_ctx {
     float bvh_scale = 0.0f; int bvh_depth = 0, bvh_n_nodes = 0, sph_root = -1;
     DevBuf mesh_soa, mesh_p1, mesh_e1, mesh_e2, mesh_nrm, tri_p1, tri_e1, tri_e2, tri_nrm, sph, sph_mat, mats, mat_fres, prim_tab, counters;
     int n_mesh = 0, n_chunks = 0, n_tris = 0, n_sph = 0, n_mats = 0;
+    int n_bvh_tris = 0, n_list = 0, n_never = 0;       // mesh triangles in the tree / on the list / that can never be hit (pt_bvh.hpp classify_triangle)
+    float sph_rmin = 0.0f, sph_reach = 0.0f;           // smallest |radius| and largest |centre|_1 of the spheres
     std::vector<float4> h_mesh_rec, h_tri_rec;   // winner records (p1 | material, e1, e2, normal) of the mesh / the scene triangles
     bool prim_dirty = true;                      // prim_tab = h_mesh_rec ++ h_tri_rec must be rebuilt
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
@@ -265,6 +267,8 @@ SceneView scene_view(const pt_ctx *c)
     s.bvh_nodes = (const float4 *)c->bvh_nodes.p; s.bvh_nodes_q = (const float4 *)c->bvh_nodes_q.p; s.bvh_tris = (const float4 *)c->bvh_tris.p; s.bvh_scale = c->bvh_scale;
     s.bvh_sph = (const float4 *)c->bvh_sph.p; s.sph_root = c->sph_root;
     for (int k = 0; k < 3; k++) { s.sph_bmin[k] = c->sph_bmin[k]; s.sph_bmax[k] = c->sph_bmax[k]; }
+    s.n_bvh_tris = c->mesh_bvh_ok ? c->n_bvh_tris : 0;
+    s.sph_k = kSphereReachK; s.sph_rmin = c->sph_rmin; s.sph_reach = c->sph_reach;
     return s;
 }
 
@@ -317,7 +321,7 @@ constexpr int kBvhStackExtra = 3;
 constexpr size_t kBvhLdsLimit = 80 * 1024, kBvhLdsLimitWide = 158 * 1024;
 size_t bvh_lds_bytes(const pt_ctx *c, int block)
 {
-    return (size_t)c->bvh_n_nodes * (kBvhLdsNodeVecs * 16) + (size_t)c->n_mesh * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
+    return (size_t)c->bvh_n_nodes * (kBvhLdsNodeVecs * 16) + (size_t)c->n_bvh_tris * 48 + (c->sph_root >= 0 ? (size_t)c->n_sph * 32 : 0) + (size_t)kSceneLdsVecs * 16
            + (size_t)(c->bvh_depth + kBvhStackExtra) * 4 * (size_t)block;
 }
 // The LDS-resident traversal kernels take more dynamic LDS than a kernel may by default: the cap is lifted for every
@@ -831,11 +835,30 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
         }
     c->mesh_bvh_ok = false; c->nodes_dirty = true;
     std::vector<float4> btris;
+    c->n_bvh_tris = c->n_list = c->n_never = 0;
     if (n > 0 && finite && scale < 1e18f) {
-        build_bvh(tris, n, bvh);
-        if (bvh.depth <= kBvhMaxDepth && (int)bvh.order.size() == n) {
-            btris.resize((size_t)kBvhTriVecs * n);
-            for (int j = 0; j < n; j++) {
+        // boxes grown by what the shader's float arithmetic makes of each triangle; the ones no box can stand for in leaves of
+        // their own that every ray behind the gate reaches (pt_bvh.hpp classify_triangle, attach_listed)
+        std::vector<float> grow(n);
+        std::vector<unsigned char> cls(n);
+        std::vector<int> listed;
+        for (int i = 0; i < n; i++) {
+            const float a[3] = {e1[i].x, e1[i].y, e1[i].z}, b2[3] = {e2[i].x, e2[i].y, e2[i].z};
+            cls[i] = (unsigned char)classify_triangle(a, b2, scale, grow[i]);
+            if (cls[i] == kTriListed) listed.push_back(i);
+            else if (cls[i] == kTriNever) c->n_never++;
+        }
+        c->n_list = (int)listed.size();
+        const int n_tree = n - c->n_list - c->n_never;
+        // every listed triangle costs every ray behind the gate a test: beyond kMeshListMax the brute-force kernels are the
+        // better exact path (and the only one for a mesh with nothing left for a tree)
+        const bool usable = n_tree > 0 && c->n_list <= kMeshListMax;
+        if (usable) { build_bvh(tris, n, bvh, grow.data(), cls.data()); if ((int)bvh.order.size() == n_tree) attach_listed(bvh, listed); }
+        const int n_rec = n_tree + c->n_list;
+        if (usable && bvh.depth <= kBvhMaxDepth && (int)bvh.order.size() == n_rec) {
+            c->n_bvh_tris = n_rec;
+            btris.resize((size_t)kBvhTriVecs * n_rec);
+            for (int j = 0; j < n_rec; j++) {
                 const int i = bvh.order[j];
                 float idf; std::memcpy(&idf, &i, 4);
                 float4 *r = &btris[kBvhTriVecs * (size_t)j];
@@ -901,6 +924,12 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
             }
             for (int k = 0; k < 3; k++) scale = std::max(scale, std::fabs(sph[i].position[k]) + std::fabs(sph[i].radius));
         }
+        c->sph_rmin = INFINITY; c->sph_reach = 0.0f;
+        for (int i = 0; i < n_sph && finite; i++) {
+            c->sph_rmin = std::min(c->sph_rmin, std::fabs(sph[i].radius));
+            c->sph_reach = std::max(c->sph_reach, (std::fabs(sph[i].position[0]) + std::fabs(sph[i].position[1])) + std::fabs(sph[i].position[2]));
+        }
+        if (!(c->sph_rmin < INFINITY)) c->sph_rmin = 0.0f;
         if (n_sph > 0 && finite && scale < 1e18f) {
             Bvh bvh;
             build_sphere_bvh(sph, n_sph, bvh);
@@ -1279,6 +1308,33 @@ int pt_group_finalize(pt_ctx *c)
     const int rc = rccl().CommDestroy(c->group_comm);
     c->group_comm = nullptr; c->group_world = 0; c->group_rank = 0;
     if (rc) return fail(c, PT_E_HIP, "ncclCommDestroy: %s", rccl().GetErrorString(rc));
+    return PT_OK;
+}
+
+int pt_classify_mesh(const PtTriangle *tris, int n, int *in_tree, int *listed, int *never, float *max_growth)
+{
+    if (n < 0 || (n > 0 && !tris)) return PT_E_INVALID;
+    float scale = 0.0f;
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            const float v[3] = {tris[i].p1[k], tris[i].p2[k], tris[i].p3[k]};
+            for (float x : v) { if (!std::isfinite(x)) return PT_E_INVALID; scale = std::max(scale, std::fabs(x)); }
+        }
+    int cnt[3] = {0, 0, 0};
+    float big = 0.0f;
+    for (int i = 0; i < n; i++) {
+        float4 p1, e1, e2, nr;
+        tri_precompute(tris[i], p1, e1, e2, nr);
+        const float a[3] = {e1.x, e1.y, e1.z}, b[3] = {e2.x, e2.y, e2.z};
+        float g;
+        const TriClass c = classify_triangle(a, b, scale, g);
+        cnt[c]++;
+        if (c == kTriTree) big = std::max(big, g);
+    }
+    if (in_tree) *in_tree = cnt[kTriTree];
+    if (listed) *listed = cnt[kTriListed];
+    if (never) *never = cnt[kTriNever];
+    if (max_growth) *max_growth = big;
     return PT_OK;
 }
 

@@ -283,15 +283,97 @@ inline bool quantise_bvh4(const BvhNode4 &w, BvhNode4Q &q)
     return true;
 }
 
-inline void build_bvh(const PtTriangle *tris, int n, Bvh &out)
+// What the float evaluation of rt.comp:153-173 makes of a mesh triangle, as far as a bounding box is concerned.  The test
+// divides by det = e1 . (d x e2) = |d| |e1 x e2| cos(phi) and scales u, v and t by the quotient: a relative error of
+// c eps |e1||e2| / (|e1 x e2| cos(phi)) in det moves the accepted region in the triangle's plane by that fraction of the
+// triangle's size (measured: tools/fuzz_bvh.py, profiles/r3_exactness).  The box of a triangle is therefore grown by
+// kSliverGrow * (longest edge) / sin(angle at p1) on every side -- 0.05 % of its size for a well-shaped triangle, which keeps
+// the tree exact for rays down to ~1e-3 rad from the triangle's plane, and in proportion more for slivers.  Where that growth
+// exceeds the mesh itself (edges parallel within rounding: det is noise and the shader reports hits anywhere along the
+// triangle's line) the triangle goes on a list that every ray behind the root-AABB gate tests, like the shader does; a
+// triangle with a zero edge at p1 can never be hit (det = +-0, t = inf * 0 = NaN fails `t > HIT_LIMIT`) and is dropped.
+constexpr double kSliverGrow = 5e-4;
+enum TriClass { kTriTree = 0, kTriListed = 1, kTriNever = 2 };
+// e1 = p2 - p1, e2 = p3 - p1 as the kernels hold them (rounded to float); extent: largest |coordinate| of the mesh
+inline TriClass classify_triangle(const float e1[3], const float e2[3], double extent, float &grow)
+{
+    const double a[3] = {e1[0], e1[1], e1[2]}, b[3] = {e2[0], e2[1], e2[2]};
+    const double l1 = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), l2 = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    grow = 0.0f;
+    if (!PT_EXACT_MARGINS) return kTriTree;
+    if (l1 == 0.0 || l2 == 0.0) return kTriNever;
+    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    const double cr = std::sqrt(cx * cx + cy * cy + cz * cz);
+    const double l3 = std::sqrt((b[0] - a[0]) * (b[0] - a[0]) + (b[1] - a[1]) * (b[1] - a[1]) + (b[2] - a[2]) * (b[2] - a[2]));
+    const double r = cr > 0.0 ? kSliverGrow * std::max(l1, std::max(l2, l3)) * (l1 * l2) / cr : INFINITY;
+    if (!(r <= 4.0 * extent)) return kTriListed;
+    grow = (float)r;
+    return kTriTree;
+}
+
+// The triangles no box can stand for (kTriListed) are given leaves whose boxes every ray meets, under a new root beside the
+// old one (whose box is the tree's own bounds): a ray behind the root-AABB gate tests all of them, like the shader, and the
+// traversal kernels need no code for it.  kBvhEverything is the largest coordinate the builder accepts (1e18 at upload), so
+// the slab tests' products stay finite (pt_kernels.hpp slab_inv).  Leaf order: the listed triangles follow the tree's.
+constexpr float kBvhEverything = 9.0e17f;
+inline void attach_listed(Bvh &bvh, const std::vector<int> &listed)
+{
+    if (listed.empty() || bvh.nodes.empty()) return;
+    std::vector<int> leaves;
+    for (size_t i = 0; i < listed.size(); i += kLeafMax) {
+        const int first = (int)bvh.order.size(), cnt = (int)std::min<size_t>(kLeafMax, listed.size() - i);
+        for (int k = 0; k < cnt; k++) bvh.order.push_back(listed[i + k]);
+        leaves.push_back(~((first << 3) | (cnt - 1)));
+    }
+    std::vector<BvhNode> top(1);       // top[0]: the new root, filled in last
+    int depth = 0;
+    struct Rec {
+        std::vector<BvhNode> &top; const std::vector<int> &leaves; int &depth;
+        int make(int lo, int hi, int d)       // child code of a balanced subtree over leaves[lo, hi); inner nodes index into `top`
+        {
+            depth = std::max(depth, d);
+            if (hi - lo == 1) return leaves[lo];
+            const int me = (int)top.size();
+            top.emplace_back();
+            const int mid = (lo + hi) / 2, l = make(lo, mid, d + 1), r = make(mid, hi, d + 1);
+            BvhNode &nd = top[me];
+            for (int k = 0; k < 3; k++) { nd.lmin[k] = nd.rmin[k] = -kBvhEverything; nd.lmax[k] = nd.rmax[k] = kBvhEverything; }
+            nd.left = l; nd.right = r; nd.pad0 = nd.pad1 = 0;
+            return me;
+        }
+    } rec{top, leaves, depth};
+    const int sub = rec.make(0, (int)leaves.size(), 1);
+    const int shift = (int)top.size();
+    BvhNode root;
+    const BvhNode &old = bvh.nodes[0];
+    for (int k = 0; k < 3; k++) {
+        root.lmin[k] = -kBvhEverything; root.lmax[k] = kBvhEverything;
+        root.rmin[k] = std::min(old.lmin[k], old.rmin[k]); root.rmax[k] = std::max(old.lmax[k], old.rmax[k]);
+    }
+    root.left = sub; root.right = shift; root.pad0 = root.pad1 = 0;
+    top[0] = root;
+    for (BvhNode nd : bvh.nodes) {
+        if (nd.left >= 0) nd.left += shift;
+        if (nd.right >= 0) nd.right += shift;
+        top.push_back(nd);
+    }
+    bvh.nodes.swap(top);
+    bvh.depth = std::max(bvh.depth + 1, depth + 1);
+}
+
+// grow / cls (optional, per triangle): box growth and class from classify_triangle; only kTriTree triangles enter the tree
+inline void build_bvh(const PtTriangle *tris, int n, Bvh &out, const float *grow = nullptr, const unsigned char *cls = nullptr)
 {
     using namespace bvh_detail;
-    Builder b; b.refs.resize(std::max(0, n));
+    Builder b; b.refs.reserve(std::max(0, n));
     for (int i = 0; i < n; i++) {
-        Ref &r = b.refs[i];
+        if (cls && cls[i] != kTriTree) continue;
+        Ref r;
         r.b.reset(); r.b.grow(tris[i].p1); r.b.grow(tris[i].p2); r.b.grow(tris[i].p3);
         for (int k = 0; k < 3; k++) r.c[k] = 0.5f * r.b.mn[k] + 0.5f * r.b.mx[k];
+        if (grow) for (int k = 0; k < 3; k++) { r.b.mn[k] -= grow[i]; r.b.mx[k] += grow[i]; }
         r.idx = i;
+        b.refs.push_back(r);
     }
     build_from_refs(b, out);
 }

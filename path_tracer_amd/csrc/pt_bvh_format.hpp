@@ -28,6 +28,15 @@ constexpr int kBvhNodeVecs = kBvhWide ? 8 : 4;    // float4 per inner node in gl
 // gather in which every lane reads its own node
 constexpr int kBvhLdsNodeVecs = kBvhWide ? 7 : 4;
 constexpr int kBvhTriVecs = 4;                    // float4 per leaf-ordered triangle record in global memory: p1|index, e1|material, e2, normal
+// mesh triangles no bounding box can stand for (pt_bvh.hpp classify_triangle) are tested one by one; more of them than this
+// and the mesh is traced by the brute-force kernels instead
+constexpr int kMeshListMax = 64;
+// rt.comp:126-146 accepts rays that pass a sphere of radius r at a distance up to sqrt(r^2 + k |o - c|^2) from its centre, k ~ 10 eps
+// (rounding of hb^2 - a c); the traversal's margin uses 16 eps
+#ifndef PT_EXACT_MARGINS
+#define PT_EXACT_MARGINS 1        // 0: A/B builds without the triangle classes and the sphere margin (not exact for slivers / far spheres)
+#endif
+constexpr float kSphereReachK = PT_EXACT_MARGINS ? 1.0e-6f : 0.0f;
 constexpr float kBvhFarBox = 3.0e38f;             // both corners of an unused child slot: no ray's slab test reaches it (see pt_bvh.hpp)
 constexpr int kSphereLeaf = 1 << 30; // leaf-code flag: the leaf holds spheres (records of the sphere tree), not mesh triangles
 }  // namespace pt

@@ -85,6 +85,10 @@ struct SceneView {
     const float4 *bvh_sph;    // sphere tree leaves, 2 x float4 per sphere in leaf order: (centre, radius), (bits(sphere index), -, -, -)
     float sph_bmin[3], sph_bmax[3];   // bounds of all spheres (centre -+ |radius|); read once per workgroup (stage_scene_lds)
     int sph_root;             // node index of the sphere tree's root in bvh_nodes, -1: spheres are scanned one by one
+    int n_bvh_tris;           // triangles in the tree (= records in bvh_tris): n_mesh minus the ones the shader can never hit
+    // Spheres seen from far away: rt.comp:126-146 reports hits up to sqrt(r^2 + k |o - c|^2) - r outside the sphere; the sphere
+    // tree's slab tests get that much more margin per ray, from the smallest radius and the farthest centre (|.|_1)
+    float sph_k, sph_rmin, sph_reach;     // the trace kernels read them from LDS too
 };
 
 // one sample's radiance in the workspace: three floats (the alpha the shader stores is the constant 1)
@@ -843,7 +847,7 @@ __device__ __forceinline__ void trace_items_body(const SceneView &sc, const Fram
 // In front of them, always: the shading parameters that are read once per path or per pixel (sky, jitter scale, origin
 // offset, pixel-centre offset) -- as kernel arguments they would sit in SGPRs through the traversal loops, where the
 // kernel already spills; here they cost one ds_read at the point of use.  (sky | jitter_scale), (sky_emit | origin_offset),
-// (pix_off, -, -, -), then the box of all spheres (min, max).
+// (pix_off, sph_k, sph_rmin, sph_reach), then the box of all spheres (min, max).
 constexpr int kShadeLdsVecs = 5;
 constexpr int kSceneLdsTris = 16;                                  // scenes with more triangles keep the scalar path
 constexpr int kSceneLdsVecs = kShadeLdsVecs + 3 * kSceneLdsTris + 5;
@@ -852,7 +856,7 @@ __device__ __forceinline__ bool stage_scene_lds(float4 *dst, const SceneView &sc
     if (tid == 0) {
         dst[0] = make_float4(sc.sh.sky[0], sc.sh.sky[1], sc.sh.sky[2], sc.sh.jitter_scale);
         dst[1] = make_float4(sc.sh.sky_emit[0], sc.sh.sky_emit[1], sc.sh.sky_emit[2], sc.sh.origin_offset);
-        dst[2] = make_float4(sc.sh.pix_off, 0.0f, 0.0f, 0.0f);
+        dst[2] = make_float4(sc.sh.pix_off, sc.sph_k, sc.sph_rmin, sc.sph_reach);
         dst[3] = make_float4(sc.sph_bmin[0], sc.sph_bmin[1], sc.sph_bmin[2], 0.0f);      // the box of all spheres (sphere tree's root)
         dst[4] = make_float4(sc.sph_bmax[0], sc.sph_bmax[1], sc.sph_bmax[2], 0.0f);
     }
@@ -961,7 +965,7 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
     // closest hit: scene primitives (s_t, s_id); mesh traversal / final result (best_t, best_id)
     float s_t = kInfinity, best_t = kInfinity;
     int s_id = -1, best_id = -1;
-    int best_rec = 0;                 // leaf-order index of mesh triangle best_id (Store::kLeafRecords)
+    int best_rec = -1;                // leaf-order index of mesh triangle best_id (Store::kLeafRecords), -1: not from a leaf
     // resumable traversal state (see the traversal phase): position `cur`, stack height `sp` (slot 0 = kTravDone for good)
     int cur = kTravDone, sp = 1;
     stk[0] = (unsigned)kTravDone;
@@ -1310,13 +1314,18 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 n_mesh_seg += __popcll(wave_ballot(gate));
                 n_prim_mesh_seg += __popcll(wave_ballot(gate) & wave_ballot(ps.bounces == 0));
                 if (state == S_TRACE) {
+                    best_rec = -1;
                     // the mesh tree (root 0) only behind the gate, like the reference; the sphere tree whenever the ray can
                     // meet the box of all spheres -- the traversal's own conservative slab test, one node visit's worth, here
                     // where it saves the ray a whole turn of parking
                     bool sph_in = false;
                     if (SPH && sph_root >= 0) {
                         inv = V(slab_inv(ps.d.x), slab_inv(ps.d.y), slab_inv(ps.d.z));
-                        delta = 4e-6f * ((fabsf(ps.o.x) + fabsf(ps.o.y)) + (fabsf(ps.o.z) + sc.bvh_scale));
+                        const float o1 = (fabsf(ps.o.x) + fabsf(ps.o.y)) + fabsf(ps.o.z);
+                        // + the reach of the sphere test's rounding (SceneView::sph_k): k D^2 / (sqrt(r^2 + k D^2) + r), D = |o|_1 + reach
+                        const float4 sm = lds_f4(st.shade, 2);
+                        const float kd2 = sm.y * ((o1 + sm.w) * (o1 + sm.w));
+                        delta = fmaf(4e-6f, o1 + sc.bvh_scale, 1.01f * kd2 * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(sm.z, sm.z, kd2)) + sm.z));
                         const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
                         const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
                         const float4 bn = lds_f4(st.shade, 3), bx = lds_f4(st.shade, 4);
@@ -1503,10 +1512,10 @@ __global__ void __launch_bounds__(BLOCK, 4) pt_trace_items_bvh_lds(SceneView sc,
     constexpr int kBvhLdsBlock = BLOCK;
     extern __shared__ float4 bvh_lds[];
     const int n_sph_rec = SPH && sc.sph_root >= 0 ? 2 * sc.n_sph : 0;
-    float4 *nodes = bvh_lds, *tris = bvh_lds + kBvhLdsNodeVecs * n_nodes, *sph = tris + 3 * sc.n_mesh, *scene = sph + n_sph_rec;
+    float4 *nodes = bvh_lds, *tris = bvh_lds + kBvhLdsNodeVecs * n_nodes, *sph = tris + 3 * sc.n_bvh_tris, *scene = sph + n_sph_rec;
     unsigned *stack = reinterpret_cast<unsigned *>(scene + kSceneLdsVecs);
     for (int i = threadIdx.x; i < kBvhLdsNodeVecs * n_nodes; i += kBvhLdsBlock) nodes[i] = sc.bvh_nodes[(i / kBvhLdsNodeVecs) * kBvhNodeVecs + i % kBvhLdsNodeVecs];
-    for (int i = threadIdx.x; i < 3 * sc.n_mesh; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i + i / 3];      // 3 of the 4 vectors of a record
+    for (int i = threadIdx.x; i < 3 * sc.n_bvh_tris; i += kBvhLdsBlock) tris[i] = sc.bvh_tris[i + i / 3];      // 3 of the 4 vectors of a record
     for (int i = threadIdx.x; i < n_sph_rec; i += kBvhLdsBlock) sph[i] = sc.bvh_sph[i];
     if (!GEN) { sc.sh.hit_limit = kHitLimit; sc.sh.box_slack = kBoxSlack; sc.sh.flags = kShDefault; }     // see trace_items_body_bvh
     const bool staged = stage_scene_lds(scene, sc, fp, threadIdx.x, kBvhLdsBlock);

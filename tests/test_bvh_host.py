@@ -57,3 +57,32 @@ def test_non_finite_is_refused(capi):
     t = S.heightfield_mesh(4, 1).tris.copy()
     t["p3"][7][2] = np.inf
     assert capi.bvh_selftest(t)[0] == capi.PT_E_INVALID
+
+
+def test_triangle_classes_for_the_tree(capi):
+    """pt_classify_mesh (pt_bvh.hpp classify_triangle): what the shader's float triangle test can report outside a triangle
+    decides how the tree boxes it -- a small growth for well-shaped triangles, a large one for slivers, the always-tested list
+    where the edges at p1 are parallel within rounding, nothing for triangles with a zero edge at p1 (never hit)."""
+    from path_tracer_amd import scene as S
+    bunny = S.bunny_mesh(3).tris
+    rc, tree, listed, never, grow = capi.classify_mesh(bunny)
+    assert rc == 0 and (tree, listed, never) == (len(bunny), 0, 0)
+    ext = float(np.abs(np.concatenate([bunny["p1"], bunny["p2"], bunny["p3"]])).max())
+    assert 0 < grow < 0.02 * ext, "bunny1 has no sliver whose box would grow by more than 2 % of the mesh"
+    pts = np.array([
+        [[0, 0, 0], [1, 0, 0], [0, 1, 0]],            # right angle at p1: growth 5e-4 x sqrt(2)
+        [[0, 0, 0], [1, 0, 0], [2, 0, 0]],            # zero area, edges parallel: listed
+        [[0, 0, 0], [1, 0, 0], [1, 0, 0]],            # p2 == p3: listed
+        [[0, 0, 0], [0, 0, 0], [1, 1, 0]],            # p1 == p2: zero edge at p1, never hit
+        [[1, 1, 1], [1, 1, 1], [1, 1, 1]],            # a point: never hit
+        [[0, 0, 0], [1, 0, 0], [1, 1e-3, 0]],         # sliver, sin(angle at p1) = 1e-3: growth 0.5 x its length, still in the tree
+        [[0, 0, 0], [1, 0, 0], [1, 1e-5, 0]],         # sin = 1e-5: growth 50 x its length > 4 x the extent: listed
+    ], np.float32)
+    t = S.triangles_from_points(pts, 0)
+    rc, tree, listed, never, grow = capi.classify_mesh(t)
+    assert rc == 0 and (tree, listed, never) == (2, 3, 2)
+    assert abs(grow - 0.5) < 0.01
+    rc, tree, listed, never, grow = capi.classify_mesh(t[:1])
+    assert (tree, listed, never) == (1, 0, 0) and abs(grow - 5e-4 * np.sqrt(2.0)) < 1e-6
+    bad = t[:1].copy(); bad["p2"][0, 0] = np.nan
+    assert capi.classify_mesh(bad)[0] == capi.PT_E_INVALID
