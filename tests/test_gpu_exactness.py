@@ -121,7 +121,7 @@ def test_a_mesh_of_slivers_goes_to_the_brute_force_kernels(capi, fuzz, cameras):
 
 @pytest.mark.parametrize("first,kind,far", [(0, None, False), (20000, 9, False), (40000, 6, False), (30000, 10, False), (50000, None, True)])
 def test_seeded_random_scenes_traversal_equals_brute_force(capi, fuzz, first, kind, far):
-    """a slice of tools/fuzz_bvh.py (the round's campaign: 9,700 scenes, profiles/r3_exactness): 12 scenes per generator"""
+    """a slice of tools/fuzz_bvh.py (the round's campaign: 10,400 scene renders, profiles/r3_exactness): 12 scenes per generator"""
     for seed in range(first, first + 12):
         sc, cam, bounces = fuzz.random_scene(seed, kind, True if far else None)
         want, _ = fuzz.render(sc, cam, 128, 72, bounces, 3, 1, 0, True)
