@@ -147,12 +147,14 @@ def random_scene(seed, only_kind=None, far_spheres=None):
     return sc, cam, bounces
 
 
-def render(sc, cam, W, H, bounces, spp, variant, lds_block=0, no_fused=False):
+def render(sc, cam, W, H, bounces, spp, variant, lds_block=0, no_fused=False, preset=0):
     r = capi.Renderer(W, H)
     r.upload_scene(sc)
     r.SetUniformCamera(cam)
     r.SetUniform1i("maxBounces", bounces)
     r.set_tuning(0, 0, 0, variant)
+    if preset:
+        r.set_shading_params(preset=preset)           # 1: the rt.frag literal set (hit limit 0, two draws, ...): the GEN kernels
     if lds_block:
         r.set_option("lds_block", lds_block)
     if no_fused:
@@ -171,6 +173,7 @@ def main():
     ap.add_argument("--spp", type=int, default=2)
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--kind", type=int, default=None, help="mesh generator (0..10), default: random per seed")
+    ap.add_argument("--preset", type=int, default=0, help="shading preset (0 rt.comp, 1 rt.frag)")
     ap.add_argument("--far-spheres", action="store_true", help="every scene: small spheres (r 1e-4..1e-2) seen from 4..100 away")
     a = ap.parse_args()
     capi.load()
@@ -178,10 +181,10 @@ def main():
     bad, kernels, finite = 0, {}, 0
     for seed in range(a.first, a.first + a.seeds):
         sc, cam, bounces = random_scene(seed, a.kind, True if a.far_spheres else None)
-        want, _ = render(sc, cam, W, H, bounces, a.spp, 1)
+        want, _ = render(sc, cam, W, H, bounces, a.spp, 1, 0, False, a.preset)
         finite += int(np.isfinite(want).all())
         for variant, blk in ((5, 0), (6, 512), (6, 1024)):
-            got, name = render(sc, cam, W, H, bounces, a.spp, variant, blk, a.no_fused)
+            got, name = render(sc, cam, W, H, bounces, a.spp, variant, blk, a.no_fused, a.preset)
             kernels[name] = kernels.get(name, 0) + 1
             n = int((got.view(np.uint32) != want.view(np.uint32)).any(-1).sum())
             if n:
