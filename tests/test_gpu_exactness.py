@@ -128,3 +128,21 @@ def test_seeded_random_scenes_traversal_equals_brute_force(capi, fuzz, first, ki
         for variant, blk in ((5, 0), (6, 0)):
             got, name = fuzz.render(sc, cam, 128, 72, bounces, 3, variant, blk, True)
             assert bits_equal(got, want), (seed, variant, name, n_diff_pixels(got, want))
+
+
+@pytest.mark.parametrize("preset", [0, 1])
+def test_seeded_random_scenes_against_the_oracle(capi, fuzz, preset):
+    """a slice of tools/fuzz_oracle.py (the round's campaign: 10,970 scenes, 0 differences): the default kernel choice and the
+    brute-force kernel against oracle/pt_oracle.c on scenes far from the fixtures"""
+    import oracle_py as O
+    n = 0
+    for seed in range(500000 + 1000 * preset, 500000 + 1000 * preset + 40):
+        sc, cam, bounces = fuzz.random_scene(seed)
+        if len(sc.mesh_tris) > 2000:
+            continue
+        want = O.Oracle(sc, cam, 96, 56, bounces, preset=preset).render(1, 2)
+        for variant in (0, 1):
+            got, name = fuzz.render(sc, cam, 96, 56, bounces, 2, variant, 0, False, preset)
+            assert bits_equal(got, want), (seed, variant, name, n_diff_pixels(got, want))
+        n += 1
+    assert n >= 25
