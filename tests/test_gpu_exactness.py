@@ -146,3 +146,15 @@ def test_seeded_random_scenes_against_the_oracle(capi, fuzz, preset):
             assert bits_equal(got, want), (seed, variant, name, n_diff_pixels(got, want))
         n += 1
     assert n >= 25
+
+
+def test_seeded_scheduling_cases_equal_the_frame_loop(capi):
+    """a slice of tools/fuzz_sched.py (the round's campaign: 4,400 cases x 3 routes, 0 differences): random image sizes, pass
+    ranges, passes per work item, workspace limits, waves per CU, scheduling options and kernel variants through pt_render,
+    pt_render_static and a split pair of pt_render calls, against one brute-force dispatch per pass"""
+    spec = importlib.util.spec_from_file_location("fuzz_sched", os.path.join(ROOT, "tools", "fuzz_sched.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    sc_list = m.scenes()
+    for case in range(40):
+        assert m.run_case(case, sc_list) == 0, case

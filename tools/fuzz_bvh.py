@@ -104,7 +104,7 @@ def random_mesh(rng, n_mats, only_kind=None):
     return S.Mesh(tris, S.Mesh.gen_bounding_box(tris), int(tris["materialIndex"][0]))
 
 
-def random_scene(seed, only_kind=None, far_spheres=None):
+def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False):
     rng = np.random.default_rng(seed)
     n_mats = int(rng.integers(1, 7))
     sc = S.Scene(materials=random_materials(rng, n_mats))
@@ -144,6 +144,13 @@ def random_scene(seed, only_kind=None, far_spheres=None):
     d = np.array([np.cos(np.radians(yaw)) * np.cos(np.radians(pitch)), np.sin(np.radians(pitch)), np.sin(np.radians(yaw)) * np.cos(np.radians(pitch))])
     cam = S.Camera(position=(centre - d * dist).astype(f32), yaw=yaw, pitch=pitch).UpdateView()
     bounces = int(rng.choice([1, 2, 4, 8, 12]))
+    if many_scene_tris:
+        # more scene triangles than the kernels stage in LDS (pt_kernels.hpp kSceneLdsTris = 16): the scalar-load route.
+        # A random stream of its own, so that the seeds above keep naming the same scenes.
+        r2 = np.random.default_rng(seed + 2 * 10**9)
+        for _ in range(int(r2.integers(17, 40))):
+            c = centre + r2.uniform(-2, 2, 3)
+            sc.add_triangle(c + r2.normal(0, 0.5, 3), c + r2.normal(0, 0.5, 3), c + r2.normal(0, 0.5, 3), int(r2.integers(0, n_mats)))
     return sc, cam, bounces
 
 
@@ -174,13 +181,14 @@ def main():
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--kind", type=int, default=None, help="mesh generator (0..10), default: random per seed")
     ap.add_argument("--preset", type=int, default=0, help="shading preset (0 rt.comp, 1 rt.frag)")
+    ap.add_argument("--many-scene-tris", action="store_true", help="17..39 more scene triangles per scene (beyond the LDS-staged 16)")
     ap.add_argument("--far-spheres", action="store_true", help="every scene: small spheres (r 1e-4..1e-2) seen from 4..100 away")
     a = ap.parse_args()
     capi.load()
     W, H = a.size
     bad, kernels, finite = 0, {}, 0
     for seed in range(a.first, a.first + a.seeds):
-        sc, cam, bounces = random_scene(seed, a.kind, True if a.far_spheres else None)
+        sc, cam, bounces = random_scene(seed, a.kind, True if a.far_spheres else None, a.many_scene_tris)
         want, _ = render(sc, cam, W, H, bounces, a.spp, 1, 0, False, a.preset)
         finite += int(np.isfinite(want).all())
         for variant, blk in ((5, 0), (6, 512), (6, 1024)):

@@ -25,15 +25,10 @@ def scenes():
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=200)
-    ap.add_argument("--first", type=int, default=0)
-    a = ap.parse_args()
-    capi.load()
-    sc_list = scenes()
+def run_case(case, sc_list):
+    """one seeded case; returns the number of routes whose image differs from the frame loop's (and prints them)"""
     bad = 0
-    for case in range(a.first, a.first + a.cases):
+    if True:
         rng = np.random.default_rng(case)
         name, sc, cam = sc_list[int(rng.integers(0, len(sc_list)))]
         W, H = int(rng.integers(8, 420)), int(rng.integers(8, 260))
@@ -95,6 +90,19 @@ def main():
                 print(f"case {case}: {route} differs in {n} pixels: scene {name} {W}x{H} passes {first}+{spp} bounces {bounces} variant {variant} "
                       f"ppi {ppi} ws {ws} wpc {wpc} opts {opts} kernel {r.kernel_name()}", flush=True)
             r.close()
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--first", type=int, default=0)
+    a = ap.parse_args()
+    capi.load()
+    sc_list = scenes()
+    bad = 0
+    for case in range(a.first, a.first + a.cases):
+        bad += run_case(case, sc_list)
         if (case - a.first) % 25 == 24:
             print(f"... {case - a.first + 1} cases, {bad} differences so far", flush=True)
     print(f"fuzz_sched: {a.cases} cases from {a.first}: {bad} differing renders", flush=True)
