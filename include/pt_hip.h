@@ -225,7 +225,7 @@ int pt_bvh_selftest(const PtTriangle *tris, int n_tris, int *n_nodes, int *depth
  * builds the tree.  The float evaluation of rt.comp:153-173 reports hits outside a triangle whose edges at p1
  * are nearly parallel; the tree's box of every triangle is grown by 5e-4 x (longest edge) / sin(angle at p1), triangles for
  * which that exceeds four times the mesh's extent get leaves that every ray behind the root-AABB gate reaches (`listed`; more
- * than 64 of them and the mesh is traced by the brute-force kernels), and triangles with a zero edge at p1, which the shader
+ * than 64 of them and than half of the mesh, and the mesh is traced by the brute-force kernels), and triangles with a zero edge at p1, which the shader
  * can never hit, are left out (`never`).  max_growth: largest growth among the triangles in the tree.  Any output may be NULL. */
 int pt_classify_mesh(const PtTriangle *tris, int n_tris, int *in_tree, int *listed, int *never, float *max_growth);
 /* name of the library's default dominant kernel (for profiles/) */

@@ -850,9 +850,10 @@ int pt_upload_mesh(pt_ctx *c, const PtTriangle *tris, int n, const PtNode *nodes
         }
         c->n_list = (int)listed.size();
         const int n_tree = n - c->n_list - c->n_never;
-        // every listed triangle costs every ray behind the gate a test: beyond kMeshListMax the brute-force kernels are the
-        // better exact path (and the only one for a mesh with nothing left for a tree)
-        const bool usable = n_tree > 0 && c->n_list <= kMeshListMax;
+        // every listed triangle costs every ray behind the gate a test: the tree pays while they are few (kMeshListMax) or at
+        // most half of the mesh -- beyond that the brute-force kernels are the better exact path (and the only one for a mesh
+        // with nothing left for a tree)
+        const bool usable = n_tree > 0 && (c->n_list <= kMeshListMax || c->n_list <= n / 2);
         if (usable) { build_bvh(tris, n, bvh, grow.data(), cls.data()); if ((int)bvh.order.size() == n_tree) attach_listed(bvh, listed); }
         const int n_rec = n_tree + c->n_list;
         if (usable && bvh.depth <= kBvhMaxDepth && (int)bvh.order.size() == n_rec) {

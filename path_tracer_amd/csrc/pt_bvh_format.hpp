@@ -28,8 +28,8 @@ constexpr int kBvhNodeVecs = kBvhWide ? 8 : 4;    // float4 per inner node in gl
 // gather in which every lane reads its own node
 constexpr int kBvhLdsNodeVecs = kBvhWide ? 7 : 4;
 constexpr int kBvhTriVecs = 4;                    // float4 per leaf-ordered triangle record in global memory: p1|index, e1|material, e2, normal
-// mesh triangles no bounding box can stand for (pt_bvh.hpp classify_triangle) are tested one by one; more of them than this
-// and the mesh is traced by the brute-force kernels instead
+// mesh triangles no bounding box can stand for (pt_bvh.hpp classify_triangle) sit in leaves every ray reaches; more of them than
+// this AND than half of the mesh, and the mesh is traced by the brute-force kernels instead
 constexpr int kMeshListMax = 64;
 // rt.comp:126-146 accepts rays that pass a sphere of radius r at a distance up to sqrt(r^2 + k |o - c|^2) from its centre, k ~ 10 eps
 // (rounding of hb^2 - a c); the traversal's margin uses 16 eps

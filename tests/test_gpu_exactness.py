@@ -108,15 +108,28 @@ def test_bunny_with_slivers_and_zero_area_triangles(capi, fuzz, cameras, seed):
 
 
 def test_a_mesh_of_slivers_goes_to_the_brute_force_kernels(capi, fuzz, cameras):
-    """more than 64 triangles that every ray would have to test: the tree is refused, the image is the brute-force one"""
+    """more triangles that every ray has to test than 64 and than half of the mesh: the tree is refused, the image is the
+    brute-force one; with fewer of them than half the mesh the tree is used and must give the same image"""
     from path_tracer_amd import scene as S
-    sc, cam, bounces = fuzz.random_scene(20011, 9)
-    rc, in_tree, listed, never, _ = capi.classify_mesh(sc.mesh.tris)
-    assert listed > 64
-    r = make(capi, sc, cam, 128, 72, bounces, 0)
-    r.render(1, 2)
-    assert r.kernel_name().startswith("pt_trace_items") and "bvh" not in r.kernel_name()
-    r.close()
+    rng = np.random.default_rng(5)
+    p = fuzz.soup(rng, 400, (0.0, 0.4, 0.0), 0.8, 0.05, 0.4)
+    zero = p.copy()
+    zero[:, 2] = zero[:, 1]                                # p2 == p3: parallel edges
+    cam, W, H, B = cameras["bench"], 160, 88, 4
+    for n_zero, tree in ((300, False), (150, True)):
+        tris = S.triangles_from_points(np.concatenate([zero[:n_zero], p[n_zero:]]), 1)
+        rc, in_tree, listed, never, _ = capi.classify_mesh(tris)
+        assert (in_tree, listed, never) == (400 - n_zero, n_zero, 0)
+        sc = S.default_scene(S.Mesh(tris, S.Mesh.gen_bounding_box(tris), 1))
+        ref = make(capi, sc, cam, W, H, B, 1)
+        ref.render(1, 3)
+        want = ref.read_accum()
+        ref.close()
+        r = make(capi, sc, cam, W, H, B, 0)
+        r.render(1, 3)
+        assert ("bvh" in r.kernel_name()) == tree, r.kernel_name()
+        assert bits_equal(r.read_accum(), want)
+        r.close()
 
 
 @pytest.mark.parametrize("first,kind,far", [(0, None, False), (20000, 9, False), (40000, 6, False), (30000, 10, False), (50000, None, True)])
