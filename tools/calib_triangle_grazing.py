@@ -35,11 +35,13 @@ for sigma in (1.0,0.3):
         t0=np.nanmax(np.minimum(A,B),axis=1); t1=np.nanmin(np.maximum(A,B),axis=1)
         t0=np.maximum(t0,0)
         return ~((t0<=t1)&(t0<=T*1.001+g[:,0])), t0, t1
+    emax=np.maximum(np.maximum(np.linalg.norm(e1[idx].astype(np.float64),axis=1),np.linalg.norm(e2[idx].astype(np.float64),axis=1)),np.linalg.norm((e2[idx]-e1[idx]).astype(np.float64),axis=1))
     v2,t0,t1=viol(delta/2)
+    vg,_,_=viol(delta/2+5e-4*emax/sigma)
     # true t in float64
     e1D=e1[idx].astype(np.float64); e2D=e2[idx].astype(np.float64); S=O-p1f[idx].astype(np.float64)
     Q=np.cross(D,e2D); DET=(e1D*Q).sum(1); TT=(e2D*np.cross(S,e1D)).sum(1)/DET
     rel=np.abs(T-TT)/np.abs(TT)
-    print("sigma %.1f cosphi 1e%d..1e%d: hits %7d violations %5d   max rel err of t %.3g  median %.3g"%(sigma,lgc,lgc+1,len(idx),v2.sum(),rel.max(),np.median(rel)))
+    print("sigma %.1f cosphi 1e%d..1e%d: hits %7d violations %5d  with the box grown by 5e-4 emax / sigma: %5d   max rel err of t %.3g  median %.3g"%(sigma,lgc,lgc+1,len(idx),v2.sum(),vg.sum(),rel.max(),np.median(rel)))
     if v2.any():
         k=np.nonzero(v2)[0][0]; print("     e.g. t_f %.6g true t %.6g t0 %.6g t1 %.6g delta %.3g"%(T[k],TT[k],t0[k],t1[k],delta[k]))
