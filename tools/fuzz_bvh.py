@@ -88,6 +88,25 @@ def random_mesh(rng, n_mats, only_kind=None):
         return S.Mesh(t, S.Mesh.gen_bounding_box(t), int(t["materialIndex"][0]))
     elif kind == 8:
         p = soup(rng, n, (0, 0.5, 0), 0.3, 0.2, 1.5)                         # large overlapping triangles: deep, fat leaves
+    elif kind == 11:
+        # (only with --kind 11) the case the margins do not cover by construction: rays within 1e-3 rad of a
+        # tessellated plane -- the float t of an edge-on hit is off by per cents -- with a second sheet close behind it
+        g = int(rng.choice([4, 12, 30]))
+        u, v = np.meshgrid(np.linspace(-1, 1, g + 1), np.linspace(-1, 1, g + 1), indexing="ij")
+        quad = []
+        for i in range(g):
+            for j in range(g):
+                a, b, c, d = (u[i, j], v[i, j]), (u[i + 1, j], v[i + 1, j]), (u[i + 1, j + 1], v[i + 1, j + 1]), (u[i, j + 1], v[i, j + 1])
+                quad += [[a, b, c], [a, c, d]]
+        q = np.asarray(quad, np.float64)
+        flat = np.zeros((len(q), 3, 3))
+        flat[..., 0], flat[..., 2] = q[..., 0], q[..., 1]
+        gap = float(np.exp(rng.uniform(np.log(1e-5), np.log(1e-2))))
+        both = np.concatenate([flat, flat + np.array([0.0, -gap, 0.0])])
+        # a random rotation, so that the planes are not axis-aligned (boxes with volume), about the origin
+        m, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        p = (both @ m.T).astype(f32)
+        globals()["_plane_frame"] = m
     else:
         # slivers: the angle at p1 log-uniform from 1e-7 rad up (kind 9: every triangle, kind 10: one in ten), the float
         # evaluation of rt.comp:153-173 then reports hits well outside the triangle
@@ -143,6 +162,15 @@ def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False):
     yaw, pitch = float(rng.uniform(0, 360)), float(rng.uniform(-60, 60))
     d = np.array([np.cos(np.radians(yaw)) * np.cos(np.radians(pitch)), np.sin(np.radians(pitch)), np.sin(np.radians(yaw)) * np.cos(np.radians(pitch))])
     cam = S.Camera(position=(centre - d * dist).astype(f32), yaw=yaw, pitch=pitch).UpdateView()
+    if only_kind == 11:
+        # the camera a hair above the upper sheet, outside it, looking along it: primary rays at 1e-6 .. 1e-2 rad to the plane
+        m = globals()["_plane_frame"]
+        along = m @ np.array([np.cos(0.3), 0.0, np.sin(0.3)])
+        up = m @ np.array([0.0, 1.0, 0.0])
+        h = float(np.exp(rng.uniform(np.log(1e-6), np.log(1e-2))))
+        pos = -along * 1.6 + up * h
+        yaw = float(np.degrees(np.arctan2(along[2], along[0]))); pitch = float(np.degrees(np.arcsin(np.clip(along[1], -1, 1))))
+        cam = S.Camera(position=pos.astype(f32), yaw=yaw, pitch=pitch).UpdateView()
     bounces = int(rng.choice([1, 2, 4, 8, 12]))
     if many_scene_tris:
         # more scene triangles than the kernels stage in LDS (pt_kernels.hpp kSceneLdsTris = 16): the scalar-load route.
