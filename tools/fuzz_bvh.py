@@ -48,6 +48,7 @@ def soup(rng, n, centre, spread, lo, hi):
 
 def random_mesh(rng, n_mats, only_kind=None):
     kind = int(rng.integers(0, 11)) if only_kind is None else only_kind
+    frame = None                                                             # generator 11: the sheets' orientation, for the camera
     n = int(rng.choice([1, 2, 3, 7, 64, 300, 1500, 6000]))
     if kind == 0:
         p = soup(rng, n, (0, 0.5, 0), 1.0, 0.02, 0.3)
@@ -106,7 +107,7 @@ def random_mesh(rng, n_mats, only_kind=None):
         # a random rotation, so that the planes are not axis-aligned (boxes with volume), about the origin
         m, _ = np.linalg.qr(rng.normal(size=(3, 3)))
         p = (both @ m.T).astype(f32)
-        globals()["_plane_frame"] = m
+        frame = m
     else:
         # slivers: the angle at p1 log-uniform from 1e-7 rad up (kind 9: every triangle, kind 10: one in ten), the float
         # evaluation of rt.comp:153-173 then reports hits well outside the triangle
@@ -120,7 +121,9 @@ def random_mesh(rng, n_mats, only_kind=None):
         p = p.astype(f32)
     tris = S.triangles_from_points(p, 0)
     tris["materialIndex"] = rng.integers(0, n_mats, len(tris))
-    return S.Mesh(tris, S.Mesh.gen_bounding_box(tris), int(tris["materialIndex"][0]))
+    mesh = S.Mesh(tris, S.Mesh.gen_bounding_box(tris), int(tris["materialIndex"][0]))
+    mesh.frame = frame
+    return mesh
 
 
 def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False):
@@ -164,7 +167,7 @@ def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False):
     cam = S.Camera(position=(centre - d * dist).astype(f32), yaw=yaw, pitch=pitch).UpdateView()
     if only_kind == 11:
         # the camera a hair above the upper sheet, outside it, looking along it: primary rays at 1e-6 .. 1e-2 rad to the plane
-        m = globals()["_plane_frame"]
+        m = sc.mesh.frame
         along = m @ np.array([np.cos(0.3), 0.0, np.sin(0.3)])
         up = m @ np.array([0.0, 1.0, 0.0])
         h = float(np.exp(rng.uniform(np.log(1e-6), np.log(1e-2))))
