@@ -931,6 +931,7 @@ int pt_upload_scene(pt_ctx *c, const PtMaterial *mats, int n_mats, const PtSpher
             c->sph_reach = std::max(c->sph_reach, (std::fabs(sph[i].position[0]) + std::fabs(sph[i].position[1])) + std::fabs(sph[i].position[2]));
         }
         if (!(c->sph_rmin < INFINITY)) c->sph_rmin = 0.0f;
+        c->sph_rmin = std::max(c->sph_rmin, 1e-30f);      // the margin divides by sqrt(r^2 + k D^2) + r: never 0 / 0 (a point sphere seen from its centre)
         if (n_sph > 0 && finite && scale < 1e18f) {
             Bvh bvh;
             build_sphere_bvh(sph, n_sph, bvh);

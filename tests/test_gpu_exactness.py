@@ -171,3 +171,30 @@ def test_seeded_scheduling_cases_equal_the_frame_loop(capi):
     sc_list = m.scenes()
     for case in range(40):
         assert m.run_case(case, sc_list) == 0, case
+
+
+def test_point_sphere_at_the_origin_seen_from_the_origin(capi):
+    """the sphere margin's k D^2 / (sqrt(r^2 + k D^2) + r) with r = 0 and D = 0 must not turn the traversal's margins into NaN:
+    radius-0 spheres at the origin, the camera at the origin (the shader reports a hit at t = 0 for every ray: the tree must too)"""
+    from path_tracer_amd import scene as S
+    sc = S.Scene(materials=S.default_materials())
+    sc.add_sphere((0.0, 0.0, 0.0), 0.0, 1)
+    for k in range(40):
+        sc.add_sphere((0.0, 0.0, 0.0), 0.0, 1)             # enough records for a sphere tree
+    sc.spheres["position"][1:] = 0.0
+    sc.spheres["position"][1, 0] = 2.0                     # one real sphere in front of the camera (yaw 0 looks down +x)
+    sc.spheres["radius"][1] = 0.5
+    cam = S.Camera(position=np.zeros(3, np.float32), yaw=0.0, pitch=0.0).UpdateView()
+    W, H = 96, 56
+    ref = make(capi, sc, cam, W, H, 3, 1)
+    ref.render(1, 2)
+    want = ref.read_accum()
+    ids, ts, _, _ = ref.read_primary_hits(1)
+    # rt.comp:126-146 accepts `t1 > -HIT_LIMIT`: the point sphere the camera sits in is hit by every primary ray at t = 0
+    assert (ids == 0).all() and (ts == 0.0).all()
+    ref.close()
+    r = make(capi, sc, cam, W, H, 3, 0)
+    r.render(1, 2)
+    assert "bvh" in r.kernel_name()
+    assert bits_equal(r.read_accum(), want)
+    r.close()
