@@ -126,7 +126,7 @@ def random_mesh(rng, n_mats, only_kind=None):
     return mesh
 
 
-def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False):
+def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False, scale=1.0):
     rng = np.random.default_rng(seed)
     n_mats = int(rng.integers(1, 7))
     sc = S.Scene(materials=random_materials(rng, n_mats))
@@ -182,6 +182,20 @@ def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False):
         for _ in range(int(r2.integers(17, 40))):
             c = centre + r2.uniform(-2, 2, 3)
             sc.add_triangle(c + r2.normal(0, 0.5, 3), c + r2.normal(0, 0.5, 3), c + r2.normal(0, 0.5, 3), int(r2.integers(0, n_mats)))
+    if scale != 1.0:
+        # the whole scene and the camera position times a power of ten: products near overflow (1e16) or in the denormals (1e-12)
+        k = f32(scale)
+        if sc.mesh is not None:
+            t = sc.mesh.tris.copy()
+            for name in ("p1", "p2", "p3"):
+                t[name][:, :3] *= k
+            sc.mesh = S.Mesh(t, S.Mesh.gen_bounding_box(t), sc.mesh.materialIndex)
+        for name in ("p1", "p2", "p3"):
+            sc.triangles[name][:, :3] *= k
+        sc.spheres["position"] *= k
+        sc.spheres["radius"] *= k
+        # the view rotation as it is (glm::lookAt of a position of 1e12 is 0/0, in the reference too); only the position moves
+        cam.position = (np.asarray(cam.position, np.float64) * scale).astype(f32)
     return sc, cam, bounces
 
 
@@ -213,13 +227,14 @@ def main():
     ap.add_argument("--kind", type=int, default=None, help="mesh generator (0..10), default: random per seed")
     ap.add_argument("--preset", type=int, default=0, help="shading preset (0 rt.comp, 1 rt.frag)")
     ap.add_argument("--many-scene-tris", action="store_true", help="17..39 more scene triangles per scene (beyond the LDS-staged 16)")
+    ap.add_argument("--scale", type=float, default=1.0, help="multiply every coordinate, radius and the camera position by this")
     ap.add_argument("--far-spheres", action="store_true", help="every scene: small spheres (r 1e-4..1e-2) seen from 4..100 away")
     a = ap.parse_args()
     capi.load()
     W, H = a.size
     bad, kernels, finite = 0, {}, 0
     for seed in range(a.first, a.first + a.seeds):
-        sc, cam, bounces = random_scene(seed, a.kind, True if a.far_spheres else None, a.many_scene_tris)
+        sc, cam, bounces = random_scene(seed, a.kind, True if a.far_spheres else None, a.many_scene_tris, a.scale)
         want, _ = render(sc, cam, W, H, bounces, a.spp, 1, 0, False, a.preset)
         finite += int(np.isfinite(want).all())
         for variant, blk in ((5, 0), (6, 512), (6, 1024)):

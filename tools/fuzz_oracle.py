@@ -30,13 +30,14 @@ def main():
     ap.add_argument("--preset", type=int, default=0)
     ap.add_argument("--extreme-materials", action="store_true", help="material parameters at the ends of their ranges (own random stream)")
     ap.add_argument("--many-scene-tris", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--max-tris", type=int, default=2000, help="skip scenes whose mesh the oracle would take seconds over")
     a = ap.parse_args()
     fz.capi.load()
     W, H = a.size
     bad = done = skipped = nonfinite = 0
     for seed in range(a.first, a.first + a.seeds):
-        sc, cam, bounces = fz.random_scene(seed, None, None, a.many_scene_tris)
+        sc, cam, bounces = fz.random_scene(seed, None, None, a.many_scene_tris, a.scale)
         if a.extreme_materials:
             r2 = np.random.default_rng(seed + 10**9)
             m = sc.materials
