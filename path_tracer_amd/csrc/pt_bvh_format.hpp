@@ -33,6 +33,9 @@ constexpr int kBvhTriVecs = 4;                    // float4 per leaf-ordered tri
 constexpr int kMeshListMax = 64;
 // rt.comp:126-146 accepts rays that pass a sphere of radius r at a distance up to sqrt(r^2 + k |o - c|^2) from its centre, k ~ 10 eps
 // (rounding of hb^2 - a c); the traversal's margin uses 16 eps
+#ifndef PT_SLAB_BY_SIGN
+#define PT_SLAB_BY_SIGN 1          // the wide node step reads a node's planes sorted by the ray's direction (0: min / max per axis)
+#endif
 #ifndef PT_EXACT_MARGINS
 #define PT_EXACT_MARGINS 1        // 0: A/B builds without the triangle classes and the sphere margin (not exact for slivers / far spheres)
 #endif

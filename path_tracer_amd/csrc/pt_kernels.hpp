@@ -379,6 +379,25 @@ struct BvhStore {
     // The traversal reads the first three; the resolve phase reads the record of the winning triangle again -- the line the
     // leaf step has just brought in -- instead of a fourth, cold line of the canonical table (kLeafRecords)
     static constexpr bool kLeafRecords = true;
+    // the same node with its planes sorted by the ray's direction (sx, sy, sz = 1: the ray runs towards smaller coordinates and
+    // enters every box through its max plane): near planes, far planes -- the slab test then needs no min / max per axis
+    __device__ __forceinline__ void node4_dir(int i, unsigned sx, unsigned sy, unsigned sz, float4 &nx, float4 &ny, float4 &nz, float4 &fx, float4 &fy, float4 &fz,
+                                              int &c0, int &c1, int &c2, int &c3) const
+    {
+        const float4 *n = nodes_q + 4 * (size_t)i;
+        const float4 o = n[0], k = n[1], qa = n[2];
+        const float2 qb = *reinterpret_cast<const float2 *>(n + 3);
+        c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
+        const unsigned ex = __float_as_uint(o.w);
+        const float stx = __uint_as_float((ex & 0xffu) << 23), sty = __uint_as_float((ex & 0xff00u) << 15), stz = __uint_as_float((ex & 0xff0000u) << 7);
+        const unsigned lx = __float_as_uint(qa.x), ly = __float_as_uint(qa.y), lz = __float_as_uint(qa.z);
+        const unsigned hx = __float_as_uint(qa.w), hy = __float_as_uint(qb.x), hz = __float_as_uint(qb.y);
+#define PT_DEQ(word, step, org) make_float4(fmaf((float)(((word) >> 0) & 0xffu), step, org), fmaf((float)(((word) >> 8) & 0xffu), step, org), \
+                                            fmaf((float)(((word) >> 16) & 0xffu), step, org), fmaf((float)(((word) >> 24) & 0xffu), step, org))
+        nx = PT_DEQ(sx ? hx : lx, stx, o.x); ny = PT_DEQ(sy ? hy : ly, sty, o.y); nz = PT_DEQ(sz ? hz : lz, stz, o.z);
+        fx = PT_DEQ(sx ? lx : hx, stx, o.x); fy = PT_DEQ(sy ? ly : hy, sty, o.y); fz = PT_DEQ(sz ? lz : hz, stz, o.z);
+#undef PT_DEQ
+    }
     __device__ __forceinline__ void tri(int j, float4 &p1, float4 &e1, float4 &e2) const
     {
         const float4 *t = tris + kBvhTriVecs * (size_t)j;
@@ -411,6 +430,16 @@ struct BvhLdsStore {
     {
         lds_cf4v *n = nodes + kBvhLdsNodeVecs * i;
         mnx = f4(n[0]); mny = f4(n[1]); mnz = f4(n[2]); mxx = f4(n[3]); mxy = f4(n[4]); mxz = f4(n[5]);
+        const f4v k = n[6];
+        c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
+    }
+    // planes sorted by the ray's direction (BvhStore::node4_dir): a per-lane choice of which of the six box vectors to read
+    __device__ __forceinline__ void node4_dir(int i, unsigned sx, unsigned sy, unsigned sz, float4 &nx, float4 &ny, float4 &nz, float4 &fx, float4 &fy, float4 &fz,
+                                              int &c0, int &c1, int &c2, int &c3) const
+    {
+        lds_cf4v *n = nodes + kBvhLdsNodeVecs * i;
+        nx = f4(n[3 * sx]); ny = f4(n[1 + 3 * sy]); nz = f4(n[2 + 3 * sz]);
+        fx = f4(n[3 - 3 * sx]); fy = f4(n[4 - 3 * sy]); fz = f4(n[5 - 3 * sz]);
         const f4v k = n[6];
         c0 = __float_as_int(k.x); c1 = __float_as_int(k.y); c2 = __float_as_int(k.z); c3 = __float_as_int(k.w);
     }
@@ -1050,6 +1079,12 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                 const int exit_at = n_other > 0 ? (n_mesh * fp.park_exit) >> 3 : 0;
                 const v3 nlo = V(-((ps.o.x + delta) * inv.x), -((ps.o.y + delta) * inv.y), -((ps.o.z + delta) * inv.z));
                 const v3 nhi = V(-((ps.o.x - delta) * inv.x), -((ps.o.y - delta) * inv.y), -((ps.o.z - delta) * inv.z));
+#if PT_SLAB_BY_SIGN
+                // the wide node step reads a node's planes sorted by the ray's direction: the addend that goes with the plane the
+                // ray enters through (min plane, grown outwards: nlo -- or max plane: nhi) and with the one it leaves through
+                const v3 nn = V(inv.x < 0.0f ? nhi.x : nlo.x, inv.y < 0.0f ? nhi.y : nlo.y, inv.z < 0.0f ? nhi.z : nlo.z);
+                const v3 nf = V(inv.x < 0.0f ? nlo.x : nhi.x, inv.y < 0.0f ? nlo.y : nhi.y, inv.z < 0.0f ? nlo.z : nhi.z);
+#endif
                 // One leaf's worth of primitives, read from `code_neg` (a leaf code): a sphere, or up to two triangles (independent
                 // tests: the second hides the first's latencies).  Returns how many were used.
                 auto test_leaf = [&](int code_neg) -> int {
@@ -1101,25 +1136,44 @@ __device__ __forceinline__ void trace_items_body_bvh(const SceneView &sc, const 
                         if (kBvhWide && cur >= 0) {
                             // four-wide node: the nearest child that is hit is visited next, the other hit children go on the
                             // stack -- four unconditional stores, each kept (the height moves on) only if its child counts
-                            float4 mnx, mny, mnz, mxx, mxy, mxz;
                             int c0, c1, c2, c3;
+                            const float lim = fmaf(best_t, 1.001f, delta);
+                            float e0, e1, e2, e3;
+                            bool h0, h1, h2, h3;
+#if PT_SLAB_BY_SIGN
+                            // planes sorted by the ray's direction: entry = the largest of the three near-plane distances, exit = the
+                            // smallest of the three far-plane ones; no min / max per axis (they issue at the slow VALU rate)
+                            float4 nx, ny, nz, fx, fy, fz;
+                            st.node4_dir(cur, __float_as_uint(inv.x) >> 31, __float_as_uint(inv.y) >> 31, __float_as_uint(inv.z) >> 31, nx, ny, nz, fx, fy, fz, c0, c1, c2, c3);
+                            const int top = (int)stk[(sp - 1) * kWave];
+                            n_bvh_nodes++;
+#define PT_SLOT(k, h, e, extra) { const float a0 = __builtin_fmaxf(__builtin_fmaxf(fmaf(nx.k, inv.x, nn.x), fmaf(ny.k, inv.y, nn.y)), fmaf(nz.k, inv.z, nn.z)); \
+                                  const float a1 = __builtin_fminf(__builtin_fminf(fmaf(fx.k, inv.x, nf.x), fmaf(fy.k, inv.y, nf.y)), fmaf(fz.k, inv.z, nf.z)) * 1.000001f; \
+                                  h = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (extra); e = a0; }
+                            PT_SLOT(x, h0, e0, true)      // slots 0 and 1 are always in use
+                            PT_SLOT(y, h1, e1, true)
+                            PT_SLOT(z, h2, e2, (!Store::kChildTest || c2 != kTravDone))
+                            PT_SLOT(w, h3, e3, (!Store::kChildTest || c3 != kTravDone))
+#undef PT_SLOT
+#else
+                            float4 mnx, mny, mnz, mxx, mxy, mxz;
                             st.node4(cur, mnx, mny, mnz, mxx, mxy, mxz, c0, c1, c2, c3);
                             const int top = (int)stk[(sp - 1) * kWave];
                             n_bvh_nodes++;
-                            const float lim = fmaf(best_t, 1.001f, delta);
                             float a0, a1;
                             slab_test_fma(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, nlo, nhi, inv, a0, a1);
-                            const bool h0 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;      // slots 0 and 1 are always in use
-                            const float e0 = a0;
+                            h0 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;      // slots 0 and 1 are always in use
+                            e0 = a0;
                             slab_test_fma(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, nlo, nhi, inv, a0, a1);
-                            const bool h1 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;
-                            const float e1 = a0;
+                            h1 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim;
+                            e1 = a0;
                             slab_test_fma(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, nlo, nhi, inv, a0, a1);
-                            const bool h2 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c2 != kTravDone);
-                            const float e2 = a0;
+                            h2 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c2 != kTravDone);
+                            e2 = a0;
                             slab_test_fma(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, nlo, nhi, inv, a0, a1);
-                            const bool h3 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c3 != kTravDone);
-                            const float e3 = a0;
+                            h3 = a0 <= a1 && a1 >= sc.sh.box_slack && a0 <= lim && (!Store::kChildTest || c3 != kTravDone);
+                            e3 = a0;
+#endif
                             // nearest hit child: a running minimum over the slots; b_k = slot k took the lead from the slots before it
                             float et = h0 ? e0 : kInfinity * 4.0f;
                             int ec = c0;
