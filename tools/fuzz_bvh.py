@@ -130,7 +130,7 @@ def random_scene(seed, only_kind=None, far_spheres=None, many_scene_tris=False, 
     rng = np.random.default_rng(seed)
     n_mats = int(rng.integers(1, 7))
     sc = S.Scene(materials=random_materials(rng, n_mats))
-    if rng.random() < 0.9:
+    if rng.random() < 0.9 or only_kind == 11:
         sc.mesh = random_mesh(rng, n_mats, only_kind)
     centre = np.zeros(3)
     if sc.mesh is not None and len(sc.mesh.tris):
