@@ -1,6 +1,6 @@
 set -u
-# the round's closing profile set: rocprofv3 kernel trace + PMC passes of configs 2, 3, 5 and the two bench lines.  TAG=r3d
-TAG=${1:-r3d}
+# the round's closing profile set: rocprofv3 kernel trace + PMC passes of configs 2, 3, 5 and the two bench lines.  TAG=r3e
+TAG=${1:-r3e}
 bash tools/profile.sh $TAG 2 > gpurun_out/prof_$TAG.log 2>&1 && python3 tools/summarize_profile.py gpurun_out/prof_$TAG pt_trace_items_bvh_lds > gpurun_out/prof_$TAG/summary.json
 bash tools/profile.sh c3_$TAG 3 > gpurun_out/prof_c3_$TAG.log 2>&1 && python3 tools/summarize_profile.py gpurun_out/prof_c3_$TAG pt_trace_items_bvh > gpurun_out/prof_c3_$TAG/summary.json
 bash tools/profile.sh c5_$TAG 5 > gpurun_out/prof_c5_$TAG.log 2>&1 && python3 tools/summarize_profile.py gpurun_out/prof_c5_$TAG pt_trace_items_bvh_lds > gpurun_out/prof_c5_$TAG/summary.json
