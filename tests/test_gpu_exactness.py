@@ -198,3 +198,15 @@ def test_point_sphere_at_the_origin_seen_from_the_origin(capi):
     assert "bvh" in r.kernel_name()
     assert bits_equal(r.read_accum(), want)
     r.close()
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e6, 1e16])
+def test_seeded_random_scenes_at_extreme_scales(capi, fuzz, scale):
+    """every coordinate, radius and the camera position times a power of ten: the slab products near overflow (1e16) or the
+    triangle test's determinants in the denormals (1e-12); the quantised node's folded decoding (2^e * inv, o * inv + a) included"""
+    for seed in range(2000000, 2000012):
+        sc, cam, bounces = fuzz.random_scene(seed, None, None, False, scale)
+        want, _ = fuzz.render(sc, cam, 128, 72, bounces, 3, 1, 0, True)
+        for variant in (5, 6):
+            got, name = fuzz.render(sc, cam, 128, 72, bounces, 3, variant, 0, True)
+            assert bits_equal(got, want), (seed, variant, name, n_diff_pixels(got, want))
